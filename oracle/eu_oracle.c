@@ -1,0 +1,1478 @@
+/* TEST INFRASTRUCTURE - not product code. See eu_oracle.h for scope and the
+ * pinning status of every stage. Each function names the reference lines it
+ * restates (paths relative to /root/reference).
+ *
+ * Build: gcc -std=c11 -O2 -ffp-contract=off -fopenmp -fPIC -shared
+ * (no FMA contraction, no -ffast-math: every float operation below is one
+ * IEEE operation in the order the reference's goading back-end performs it).
+ */
+#define _GNU_SOURCE
+#include "eu_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <float.h>
+
+/* ------------------------------------------------------------------------ */
+/* set-up: extents (envutil_basic.cc:49-229)                                 */
+/* ------------------------------------------------------------------------ */
+
+double euo_get_vfov(int projection, int width, int height, double hfov)
+{
+  double vfov = 0.0;
+  switch (projection) {
+    case EUO_RECTILINEAR:
+      vfov = 2.0 * atan(height * tan(hfov / 2.0) / width);
+      break;
+    case EUO_CYLINDRICAL: {
+      double pixels_per_rad = width / hfov;
+      double h_rad = height / pixels_per_rad;
+      vfov = 2.0 * atan(h_rad / 2.0);
+      break;
+    }
+    case EUO_STEREOGRAPHIC: {
+      double w_rad = 2.0 * tan(hfov / 4.0);
+      double pixels_per_rad = width / w_rad;
+      double h_rad = height / pixels_per_rad;
+      vfov = 4.0 * atan(h_rad / 2.0);
+      break;
+    }
+    case EUO_SPHERICAL:
+    case EUO_FISHEYE:
+      vfov = hfov * height / width;
+      break;
+    default:
+      /* envutil_basic.cc:91-101: the cubemap case falls through to this */
+      vfov = hfov;
+      break;
+  }
+  return vfov;
+}
+
+double euo_get_step(int projection, int width, int height, double hfov)
+{
+  (void)height;
+  switch (projection) {
+    case EUO_RECTILINEAR:
+    case EUO_CUBEMAP:
+      return atan(2.0 * tan(hfov / 2.0) / width);
+    case EUO_BIATAN6:
+    case EUO_SPHERICAL:
+    case EUO_CYLINDRICAL:
+    case EUO_FISHEYE:
+      return hfov / width;
+    case EUO_STEREOGRAPHIC:
+      return atan(4.0 * tan(hfov / 4.0) / width);
+  }
+  return 0.0;
+}
+
+void euo_get_extent(int projection, int width, int height, double hfov,
+                    double *e)
+{
+  double x0, x1, y0, y1;
+  double alpha_x = -hfov / 2.0;
+  double beta_x = hfov / 2.0;
+  double beta_y = euo_get_vfov(projection, width, height, hfov) / 2.0;
+  double alpha_y = -beta_y;
+  switch (projection) {
+    case EUO_SPHERICAL:
+    case EUO_FISHEYE:
+      x0 = alpha_x; x1 = beta_x; y0 = alpha_y; y1 = beta_y;
+      break;
+    case EUO_CYLINDRICAL:
+      x0 = alpha_x; x1 = beta_x; y0 = tan(alpha_y); y1 = tan(beta_y);
+      break;
+    case EUO_RECTILINEAR:
+      x0 = tan(alpha_x); x1 = tan(beta_x);
+      y0 = tan(alpha_y); y1 = tan(beta_y);
+      break;
+    case EUO_STEREOGRAPHIC:
+      x0 = 2.0 * tan(alpha_x / 2.0); x1 = 2.0 * tan(beta_x / 2.0);
+      y0 = 2.0 * tan(alpha_y / 2.0); y1 = 2.0 * tan(beta_y / 2.0);
+      break;
+    case EUO_CUBEMAP:
+    case EUO_BIATAN6:
+      x0 = tan(alpha_x); x1 = tan(beta_x);
+      y0 = 6 * x0; y1 = 6 * x1;
+      break;
+    default:
+      x0 = x1 = y0 = y1 = 0.0;
+  }
+  e[0] = x0; e[1] = x1; e[2] = y0; e[3] = y1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* set-up: rotations (envutil_payload.cc:136-218, geometry.h:74-97)          */
+/* Imath is not under /root/reference: Euler<float>(roll,pitch,yaw,ZXY)      */
+/* .toQuat(), Quat::invert and Vec3*Quat follow Imath 3's published          */
+/* ImathEuler.h / ImathQuat.h (static frame, even parity, initial axis Z,    */
+/* no repetition: i=2, j=0, k=1). PARITY UNPINNED.                           */
+/* ------------------------------------------------------------------------ */
+
+static void cross3(const double *a, const double *b, double *o)
+{
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+void euo_make_r3(double roll, double pitch, double yaw, int inverse, double *m)
+{
+  /* Eulerf: the three angles narrow to float (payload.cc:152) */
+  float ax = (float)roll, ay = (float)pitch, az = (float)yaw;
+  float ti = (float)(ax * 0.5), tj = (float)(ay * 0.5), th = (float)(az * 0.5);
+  float ci = cosf(ti), cj = cosf(tj), ch = cosf(th);
+  float si = sinf(ti), sj = sinf(tj), sh = sinf(th);
+  float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+  float a[3];
+  a[2] = cj * sc - sj * cs;              /* i = 2 */
+  a[0] = (float)((cj * ss + sj * cc) * 1.0); /* j = 0, parity +1 */
+  a[1] = cj * cs - sj * sc;              /* k = 1 */
+  float qr = cj * cc + sj * ss;
+  double r = qr, v[3] = { a[0], a[1], a[2] };
+  if (inverse) {
+    double qdot = r * r + (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    r /= qdot;
+    v[0] = -v[0] / qdot; v[1] = -v[1] / qdot; v[2] = -v[2] / qdot;
+  }
+  for (int e = 0; e < 3; e++) {
+    double in[3] = { 0.0, 0.0, 0.0 }, A[3], B[3];
+    in[e] = 1.0;
+    cross3(v, in, A);
+    cross3(v, A, B);
+    for (int i = 0; i < 3; i++)
+      m[3 * e + i] = in[i] + 2.0 * (r * A[i] + B[i]);
+  }
+}
+
+/* geometry.h:80-97: every row of lhs as a linear combination of rhs rows */
+void euo_rotate_r3(const double *l, const double *r, double *o)
+{
+  double t[9];
+  for (int row = 0; row < 3; row++)
+    for (int i = 0; i < 3; i++)
+      t[3 * row + i] = (l[3 * row + 0] * r[0 + i] + l[3 * row + 1] * r[3 + i])
+                       + l[3 * row + 2] * r[6 + i];
+  memcpy(o, t, sizeof t);
+}
+
+/* ------------------------------------------------------------------------ */
+/* set-up: twining tap table (envutil_main.cc:1253-1355)                     */
+/* ------------------------------------------------------------------------ */
+
+int euo_make_spread(int w, int h, float d, float sigma, float threshold,
+                    float *out, int max_taps)
+{
+  if (w <= 2) w = 2;
+  if (h <= 0) h = w;
+  if (w * h > max_taps) return -1;
+  float wgt = (float)(1.0 / (w * h));
+  double x0 = -(w - 1.0) / (2.0 * w);
+  double dx = 1.0 / w;
+  double y0 = -(h - 1.0) / (2.0 * h);
+  double dy = 1.0 / h;
+  sigma = (float)(sigma * -x0);
+  double sum = 0.0;
+  int n = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float wf = 1.0f;
+      if (sigma > 0.0) {
+        double wx = (x0 + x * dx) / sigma;
+        double wy = (y0 + y * dy) / sigma;
+        wf = (float)exp(-sqrt(wx * wx + wy * wy));
+      }
+      out[3 * n + 0] = (float)(d * (x0 + x * dx));
+      out[3 * n + 1] = (float)(d * (y0 + y * dy));
+      out[3 * n + 2] = wf * wgt;
+      sum += wf * wgt;
+      n++;
+    }
+  if (sigma != 0.0) {
+    double th_sum = 0.0;
+    int renormalize = 0;
+    for (int i = 0; i < n; i++) {
+      out[3 * i + 2] = (float)(out[3 * i + 2] / sum);
+      if (out[3 * i + 2] >= threshold) th_sum += out[3 * i + 2];
+      else { renormalize = 1; out[3 * i + 2] = 0.0f; }
+    }
+    if (renormalize) {
+      int m = 0;
+      for (int i = 0; i < n; i++) {
+        out[3 * i + 2] = (float)(out[3 * i + 2] / th_sum);
+        if (out[3 * i + 2] > 0.0f) {
+          out[3 * m + 0] = out[3 * i + 0];
+          out[3 * m + 1] = out[3 * i + 1];
+          out[3 * m + 2] = out[3 * i + 2];
+          m++;
+        }
+      }
+      n = m;
+    }
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* b-spline basis: weight matrix (zimt/basis.h:419-545) and poles            */
+/* ------------------------------------------------------------------------ */
+
+/* value of the centred B-spline of degree n at x2/2, as the exact rational
+ * (1/n!) * sum_k (-1)^k C(n+1,k) (x - k + (n+1)/2)_+^n evaluated in
+ * long double on integers scaled by 2^n. The reference reads the same values
+ * from a table of long double literals (zimt/poles.h K0..K45). */
+static long double basis_half(int x2, int n)
+{
+  if (n == 0) return (x2 == -1 || x2 == 0) ? 1.0L : 0.0L;
+  int ax = x2 < 0 ? -x2 : x2;
+  if (ax > n) return 0.0L;
+  long double acc = 0.0L, binom = 1.0L;
+  for (int k = 0; k <= n + 1; k++) {
+    /* t = 2*(x - k) + (n+1), i.e. twice the argument */
+    long double t = (long double)(ax - 2 * k + (n + 1));
+    if (t > 0) {
+      long double p = 1.0L;
+      for (int i = 0; i < n; i++) p *= t;
+      acc += ((k & 1) ? -binom : binom) * p;
+    }
+    binom = binom * (long double)(n + 1 - k) / (long double)(k + 1);
+  }
+  long double den = 1.0L;
+  for (int i = 2; i <= n; i++) den *= i;
+  for (int i = 0; i < n; i++) den *= 2.0L;
+  return acc / den;
+}
+
+/* basis.h:419-485 restated: Taylor coefficients of each polynomial piece,
+ * built by repeated differencing of lower-degree basis values. */
+void euo_weight_matrix(int degree, float *m)
+{
+  int order = degree + 1;
+  long double line[EUO_MAX_DEGREE + 2];
+  long double faculty = 1.0L;
+  for (int row = 0; row < order; row++) {
+    if (row > 1) faculty *= row;
+    long double *first = line, *end = line + degree + 1;
+    int mm = degree - row;
+    if (mm == 0) { line[0] = 1.0L; first++; }
+    else if (degree & 1)
+      for (int x2 = -mm + 1; x2 <= mm - 1; x2 += 2) *first++ = basis_half(x2, mm);
+    else
+      for (int x2 = -mm; x2 <= mm; x2 += 2) *first++ = basis_half(x2, mm);
+    for (long double *p = first; p < end; p++) *p = 0.0L;
+    for (int d = mm; d < degree; d++) {
+      long double *put = first, *pick = put - 1;
+      while (pick >= line) { *put = *pick - *put; --put; --pick; }
+      *put = -*put;
+      first++;
+    }
+    for (int k = 0; k <= degree; k++)
+      m[k * order + row] = (float)(line[k] / faculty);
+  }
+}
+
+/* basis.h:650-690: weights for one delta; power accumulates, no Horner */
+static void weights_from_matrix(const float *m, int degree, float delta, float *w)
+{
+  int order = degree + 1;
+  for (int c = 0; c <= degree; c++) w[c] = m[c * order];
+  if (!degree) return;
+  float power = delta;
+  for (int row = 1;; row++) {
+    for (int c = 0; c <= degree; c++) w[c] += power * m[c * order + row];
+    if (row == degree) break;
+    power *= delta;
+  }
+}
+
+void euo_basis_weights(int degree, float delta, float *w)
+{
+  float m[(EUO_MAX_DEGREE + 1) * (EUO_MAX_DEGREE + 1)];
+  euo_weight_matrix(degree, m);
+  weights_from_matrix(m, degree, delta, w);
+}
+
+/* Prefilter poles: roots inside the unit circle of sum_k beta^n(k) z^(k+n/2)
+ * (zimt/poles.h tabulates them as long double literals). Computed here by
+ * Newton iteration in long double from the same polynomial; only their
+ * float value, the float gain and the horizon enter the arithmetic. */
+static long double poly_eval(const long double *c, int len, long double z, long double *dp)
+{
+  long double p = c[len - 1], d = 0.0L;
+  for (int i = len - 2; i >= 0; i--) { d = d * z + p; p = p * z + c[i]; }
+  if (dp) *dp = d;
+  return p;
+}
+
+int euo_poles(int degree, long double *poles)
+{
+  int np = degree / 2;
+  if (np == 0) return 0;
+  int n = degree, len = 2 * np + 1;
+  long double c[2 * EUO_MAX_DEGREE + 3];
+  for (int k = -np; k <= np; k++) c[k + np] = basis_half(2 * k, n);
+  /* all roots are real, negative and simple; np of them lie in (-1, 0).
+   * Walk a geometric grid from -1 towards 0, bisect every sign change,
+   * polish with Newton steps. Results come out most negative first, the
+   * order of the reference's tables. */
+  int found = 0;
+  long double za = -1.0L, pa = poly_eval(c, len, za, 0);
+  while (found < np && za < -1e-12L) {
+    long double zb = za * 0.9L, pb = poly_eval(c, len, zb, 0);
+    if ((pa < 0) != (pb < 0)) {
+      long double lo = za, hi = zb, plo = pa;
+      for (int it = 0; it < 90; it++) {
+        long double mid = 0.5L * (lo + hi), pm = poly_eval(c, len, mid, 0);
+        if ((pm < 0) == (plo < 0)) { lo = mid; plo = pm; } else hi = mid;
+      }
+      long double z = 0.5L * (lo + hi);
+      for (int it = 0; it < 4; it++) {
+        long double dp, p = poly_eval(c, len, z, &dp);
+        z -= p / dp;
+      }
+      poles[found++] = z;
+    }
+    za = zb; pa = pb;
+  }
+  return found;
+}
+
+/* ------------------------------------------------------------------------ */
+/* b-spline container (zimt/bspline.h:233-450, :759-820)                     */
+/* ------------------------------------------------------------------------ */
+
+static long left_brace(int degree, int bc)
+{
+  long n = degree / 2;
+  if (bc == EUO_REFLECT) n++;
+  else if (degree & 1) n++;
+  if (bc == EUO_PERIODIC && !(degree & 1)) n++;
+  return n;
+}
+
+static long right_brace(int degree, int bc)
+{
+  long n = degree / 2;
+  if (bc == EUO_REFLECT) { if (!(degree & 1)) n++; }
+  if (degree & 1) n++;
+  if (bc == EUO_PERIODIC) n++;
+  return n;
+}
+
+void euo_spline_geometry(int degree, int bc0, int bc1, long w, long h, long *o)
+{
+  o[2] = left_brace(degree, bc0);  o[3] = left_brace(degree, bc1);
+  o[4] = right_brace(degree, bc0); o[5] = right_brace(degree, bc1);
+  o[0] = w + o[2] + o[4];
+  o[1] = h + o[3] + o[5];
+}
+
+int euo_spline_init(euo_spline *s, float *container, long w, long h, int nch,
+                    int degree, int bc0, int bc1)
+{
+  long g[6];
+  euo_spline_geometry(degree, bc0, bc1, w, h, g);
+  s->data = container;
+  s->shape[0] = g[0]; s->shape[1] = g[1];
+  s->stride[0] = 1;   s->stride[1] = g[0];
+  s->left[0] = g[2];  s->left[1] = g[3];
+  s->right[0] = g[4]; s->right[1] = g[5];
+  s->core[0] = w;     s->core[1] = h;
+  s->bc[0] = bc0;     s->bc[1] = bc1;
+  s->degree = degree;
+  s->nch = nch;
+  return 0;
+}
+
+static float *core_px(const euo_spline *s, long x, long y)
+{
+  return s->data + ((s->left[1] + y) * s->stride[1] + (s->left[0] + x) * s->stride[0]) * s->nch;
+}
+
+void euo_spline_set_core(euo_spline *s, const float *core)
+{
+  for (long y = 0; y < s->core[1]; y++)
+    memcpy(core_px(s, 0, y), core + y * s->core[0] * s->nch,
+           sizeof(float) * s->core[0] * s->nch);
+}
+
+/* zimt/brace.h:134-330, one axis, slices span the whole container */
+static void copy_slice(euo_spline *s, int axis, long to, long from)
+{
+  int other = 1 - axis;
+  long n = s->shape[other];
+  for (long i = 0; i < n; i++) {
+    float *d = s->data + (to * s->stride[axis] + i * s->stride[other]) * s->nch;
+    const float *p = s->data + (from * s->stride[axis] + i * s->stride[other]) * s->nch;
+    for (int c = 0; c < s->nch; c++) d[c] = p[c];
+  }
+}
+
+static void natural_slice(euo_spline *s, int axis, long to, long pivot, long from)
+{
+  int other = 1 - axis;
+  long n = s->shape[other];
+  for (long i = 0; i < n; i++) {
+    float *d = s->data + (to * s->stride[axis] + i * s->stride[other]) * s->nch;
+    const float *a = s->data + (pivot * s->stride[axis] + i * s->stride[other]) * s->nch;
+    const float *b = s->data + (from * s->stride[axis] + i * s->stride[other]) * s->nch;
+    for (int c = 0; c < s->nch; c++) d[c] = a[c] + a[c] - b[c];
+  }
+}
+
+static void zero_slice(euo_spline *s, int axis, long to)
+{
+  int other = 1 - axis;
+  for (long i = 0; i < s->shape[other]; i++) {
+    float *d = s->data + (to * s->stride[axis] + i * s->stride[other]) * s->nch;
+    for (int c = 0; c < s->nch; c++) d[c] = 0.0f;
+  }
+}
+
+static void brace_axis(euo_spline *s, int axis)
+{
+  int bc = s->bc[axis];
+  long lsz = s->left[axis], rsz = s->right[axis];
+  long w = s->shape[axis], m = w - (lsz + rsz);
+  if (m == 1) {
+    for (long i = 0; i < w; i++) if (i != lsz) copy_slice(s, axis, i, lsz);
+    return;
+  }
+  long l0 = lsz - 1, r0 = lsz + m, lp = l0 + 1, rp = r0 - 1, l1 = -1, r1 = w;
+  long lt = l0, rt = r0, ls = 0, rs = 0, ds = 1;
+  switch (bc) {
+    case EUO_PERIODIC: ls = l0 + m; rs = r0 - m; ds = -1; break;
+    case EUO_NATURAL:
+    case EUO_MIRROR:   ls = l0 + 2; rs = r0 - 2; break;
+    case EUO_CONSTANT:
+    case EUO_REFLECT:  ls = l0 + 1; rs = r0 - 1; break;
+    default: break;
+  }
+  for (long i = lsz > rsz ? lsz : rsz; i > 0; --i) {
+    if (lt > l1) {
+      switch (bc) {
+        case EUO_PERIODIC: case EUO_MIRROR: case EUO_REFLECT:
+          copy_slice(s, axis, lt, ls); break;
+        case EUO_NATURAL:  natural_slice(s, axis, lt, lp, ls); break;
+        case EUO_CONSTANT: copy_slice(s, axis, lt, lp); break;
+        case EUO_ZEROPAD:  zero_slice(s, axis, lt); break;
+        default: break;
+      }
+      --lt; ls += ds;
+    }
+    if (rt < r1) {
+      switch (bc) {
+        case EUO_PERIODIC: case EUO_MIRROR: case EUO_REFLECT:
+          copy_slice(s, axis, rt, rs); break;
+        case EUO_NATURAL:  natural_slice(s, axis, rt, rp, rs); break;
+        case EUO_CONSTANT: copy_slice(s, axis, rt, rp); break;
+        case EUO_ZEROPAD:  zero_slice(s, axis, rt); break;
+        default: break;
+      }
+      ++rt; rs -= ds;
+    }
+  }
+}
+
+void euo_brace(euo_spline *s, int axis)
+{
+  if (axis < 0) { brace_axis(s, 0); brace_axis(s, 1); }
+  else brace_axis(s, axis);
+}
+
+/* ------------------------------------------------------------------------ */
+/* recursive prefilter (zimt/recursive.h:93-104, :385-620, :631-733, :790-860) */
+/* one line of floats, element stride 'es'; math type float                  */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  int bc, npoles;
+  float pole[EUO_MAX_DEGREE / 2 + 1];
+  long double lpole[EUO_MAX_DEGREE / 2 + 1];
+  int horizon[EUO_MAX_DEGREE / 2 + 1];
+  float gain;
+} iir_t;
+
+static void iir_init(iir_t *f, int bc, int degree, long double tolerance)
+{
+  f->bc = bc;
+  f->npoles = euo_poles(degree, f->lpole);
+  long double gain = 1.0L;
+  for (int k = 0; k < f->npoles; k++) {
+    f->pole[k] = (float)f->lpole[k];
+    if (tolerance > 0)
+      f->horizon[k] = (int)ceill(logl(tolerance) / logl(fabsl(f->lpole[k])));
+    else
+      f->horizon[k] = INT_MAX;
+    gain *= (1.0L - f->lpole[k]) * (1.0L - 1.0L / f->lpole[k]);
+  }
+  f->gain = (float)gain;
+}
+
+static float icc(const iir_t *f, const float *c, long es, int M, int k)
+{
+  float z = f->pole[k], zn, z2n, iz, Sum;
+  int n, hz = f->horizon[k];
+  switch (f->bc) {
+    case EUO_NATURAL:
+      if (hz < M) {
+        float c02 = c[0] + c[0];
+        zn = z; Sum = c[0];
+        for (n = 1; n < hz; n++) { Sum += zn * (c02 - c[n * es]); zn *= z; }
+        return Sum;
+      }
+      zn = z; iz = 1.0f / z;
+      z2n = (float)powl(f->lpole[k], (long double)(M - 1));
+      Sum = ((1.0f + z) / (1.0f - z)) * (c[0] - z2n * c[(M - 1) * es]);
+      z2n *= z2n * iz;
+      for (n = 1; n <= M - 2; n++) { Sum -= (zn - z2n) * c[n * es]; zn *= z; z2n *= iz; }
+      return Sum / (1.0f - zn * zn);
+    case EUO_REFLECT:
+      if (hz < M) {
+        zn = z; Sum = c[0];
+        for (n = 0; n < hz; n++) { Sum += zn * c[n * es]; zn *= z; }
+        return Sum;
+      }
+      zn = z; iz = 1.0f / z;
+      z2n = (float)powl(f->lpole[k], (long double)(2 * M));
+      Sum = 0;
+      for (n = 0; n < M - 1; n++) { Sum += (zn + z2n) * c[n * es]; zn *= z; z2n *= iz; }
+      Sum += (zn + z2n) * c[n * es];
+      return c[0] + Sum / (1.0f - zn * zn);
+    case EUO_PERIODIC:
+      if (hz < M) {
+        zn = z; Sum = c[0];
+        for (n = M - 1; n > (M - hz); n--) { Sum += zn * c[n * es]; zn *= z; }
+      } else {
+        zn = z; Sum = c[0];
+        for (n = M - 1; n > 0; n--) { Sum += zn * c[n * es]; zn *= z; }
+        Sum /= (1.0f - zn);
+      }
+      return Sum;
+    case EUO_MIRROR:
+      /* recursive.h:321-360 */
+      if (hz < M) {
+        zn = z; Sum = c[0];
+        for (n = 1; n < hz; n++) { Sum += zn * c[n * es]; zn *= z; }
+        return Sum;
+      }
+      zn = z; iz = 1.0f / z;
+      z2n = (float)powl(f->lpole[k], (long double)(M - 1));
+      Sum = c[0] + z2n * c[(M - 1) * es];
+      z2n *= z2n * iz;
+      for (n = 1; n <= M - 2; n++) { Sum += (zn + z2n) * c[n * es]; zn *= z; z2n *= iz; }
+      return Sum / (1.0f - zn * zn);
+    case EUO_GUESS:
+      return c[0] * (float)(1.0 / (1.0 - (double)f->lpole[k]));
+    default: /* ZEROPAD: identity */
+      return c[0];
+  }
+}
+
+static float iacc(const iir_t *f, const float *c, long es, int M, int k)
+{
+  float z = f->pole[k], zn, Sum;
+  int hz = f->horizon[k];
+  switch (f->bc) {
+    case EUO_NATURAL:
+      return -(z / ((1.0f - z) * (1.0f - z))) * (c[(M - 1) * es] - z * c[(M - 2) * es]);
+    case EUO_REFLECT:
+      return c[(M - 1) * es] / (1.0f - 1.0f / z);
+    case EUO_PERIODIC:
+      if (hz < M) {
+        zn = z; Sum = c[(M - 1) * es] * z;
+        for (int n = 0; n < hz; n++) { zn *= z; Sum += zn * c[n * es]; }
+        Sum = -Sum;
+      } else {
+        zn = z; Sum = c[(M - 1) * es];
+        for (int n = 0; n < M - 1; n++) { Sum += zn * c[n * es]; zn *= z; }
+        Sum = z * Sum / (zn - 1.0f);
+      }
+      return Sum;
+    case EUO_MIRROR:
+    case EUO_GUESS:
+      /* recursive.h:362-372 */
+      return (z / (z * z - 1.0f)) * (c[(M - 1) * es] + z * c[(M - 2) * es]);
+    default:
+      return c[(M - 1) * es];
+  }
+}
+
+static void solve_line(const iir_t *f, float *x, long es, int M)
+{
+  if (M == 1 || f->npoles < 1) return;
+  float p = f->pole[0], g = f->gain, X;
+  /* in place: every input value is read before its slot is overwritten */
+  X = g * icc(f, x, es, M, 0);
+  float prev_in;
+  x[0] = X;
+  for (int n = 1; n < M; n++) { prev_in = x[n * es]; X = g * prev_in + p * X; x[n * es] = X; }
+  X = iacc(f, x, es, M, 0);
+  x[(M - 1) * es] = X;
+  for (int n = M - 2; n >= 0; n--) { X = p * (X - x[n * es]); x[n * es] = X; }
+  for (int k = 1; k < f->npoles; k++) {
+    p = f->pole[k];
+    X = icc(f, x, es, M, k);
+    x[0] = X;
+    for (int n = 1; n < M; n++) { X = x[n * es] + p * X; x[n * es] = X; }
+    X = iacc(f, x, es, M, k);
+    x[(M - 1) * es] = X;
+    for (int n = M - 2; n >= 0; n--) { X = p * (X - x[n * es]); x[n * es] = X; }
+  }
+}
+
+void euo_filter_lines(float *base, long n_lines, long line_stride, long len,
+                      long ele_stride, int bc, int degree, double tolerance)
+{
+  iir_t f;
+  iir_init(&f, bc, degree, (long double)tolerance);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < n_lines; i++)
+    solve_line(&f, base + i * line_stride, ele_stride, (int)len);
+}
+
+/* zimt/prefilter.h:133-190 + bspline.h:1017-1041: both axes over the core,
+ * tolerance = float epsilon, then brace all axes */
+void euo_prefilter(euo_spline *s, int prefilter_degree)
+{
+  if (prefilter_degree > 1) {
+    long W = s->core[0], H = s->core[1];
+    int nch = s->nch;
+    long double tol = FLT_EPSILON;
+    for (int axis = 0; axis < 2; axis++) {
+      iir_t f;
+      iir_init(&f, s->bc[axis], prefilter_degree, tol);
+      long nl = axis == 0 ? H : W, len = axis == 0 ? W : H;
+#pragma omp parallel for schedule(static)
+      for (long i = 0; i < nl; i++)
+        for (int c = 0; c < nch; c++) {
+          float *p = axis == 0 ? core_px(s, 0, i) + c : core_px(s, i, 0) + c;
+          solve_line(&f, p, s->stride[axis] * nch, (int)len);
+        }
+    }
+  }
+  euo_brace(s, -1);
+}
+
+/* environment.h:356-522: full 360x180 lat/lon image */
+void euo_spherical_prefilter(euo_spline *s, int degree)
+{
+  long W = s->core[0], H = s->core[1];
+  int nch = s->nch;
+  long half = W / 2;
+  if (degree > 1) {
+    iir_t f;
+    iir_init(&f, EUO_PERIODIC, degree, 0.0001L);
+#pragma omp parallel for schedule(static)
+    for (long y = 0; y < H; y++)
+      for (int c = 0; c < nch; c++)
+        solve_line(&f, core_px(s, 0, y) + c, nch, (int)W);
+    /* left-half column top->bottom followed by the opposite column
+     * bottom->top, filtered as one periodic line of length 2H */
+#pragma omp parallel
+    {
+      float *line = (float *)malloc(sizeof(float) * 2 * (size_t)H);
+#pragma omp for schedule(static)
+      for (long x = 0; x < half; x++)
+        for (int c = 0; c < nch; c++) {
+          for (long y = 0; y < H; y++) {
+            line[y] = core_px(s, x, y)[c];
+            line[H + y] = core_px(s, x + half, H - 1 - y)[c];
+          }
+          solve_line(&f, line, 1, (int)(2 * H));
+          for (long y = 0; y < H; y++) {
+            core_px(s, x, y)[c] = line[y];
+            core_px(s, x + half, H - 1 - y)[c] = line[H + y];
+          }
+        }
+      free(line);
+    }
+  }
+  /* over-the-pole frame rows: left half <-> right half */
+  for (long k = 0; k < s->left[1]; k++)
+    for (long x = 0; x < half; x++) {
+      memcpy(core_px(s, x, -1 - k), core_px(s, x + half, k), sizeof(float) * nch);
+      memcpy(core_px(s, x + half, -1 - k), core_px(s, x, k), sizeof(float) * nch);
+    }
+  for (long k = 0; k < s->right[1]; k++)
+    for (long x = 0; x < half; x++) {
+      memcpy(core_px(s, x, H + k), core_px(s, x + half, H - 1 - k), sizeof(float) * nch);
+      memcpy(core_px(s, x + half, H + k), core_px(s, x, H - 1 - k), sizeof(float) * nch);
+    }
+  brace_axis(s, 0);
+}
+
+/* ------------------------------------------------------------------------ */
+/* evaluator: gates (zimt/map.h), split (basis.h:102-146), offsets and the   */
+/* weighted sum (eval.h:904-1059, :1237-1300)                                */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  const float *base;      /* core origin */
+  int es[2];              /* strides in float elements */
+  int degree, nch;
+  int gate[2];            /* 0 clamp, 1 mirror, 2 periodic */
+  float lower[2], upper[2];
+  float m[(EUO_MAX_DEGREE + 1) * (EUO_MAX_DEGREE + 1)];
+} ev_t;
+
+static void ev_init(ev_t *e, const euo_spline *s, int degree)
+{
+  e->base = s->data + (s->left[1] * s->stride[1] + s->left[0] * s->stride[0]) * s->nch;
+  e->es[0] = (int)(s->nch * s->stride[0]);
+  e->es[1] = (int)(s->nch * s->stride[1]);
+  e->degree = degree;
+  e->nch = s->nch;
+  for (int a = 0; a < 2; a++) {
+    int bc = s->bc[a];
+    /* bspline.h:233-270 */
+    long double lo = 0.0L, up = (long double)(s->core[a] - 1);
+    if (bc == EUO_REFLECT || bc == EUO_PERIODIC) { lo = -0.5L; up += 0.5L; }
+    e->lower[a] = (float)lo;
+    e->upper[a] = (float)up;
+    if (s->core[a] == 1) { bc = EUO_CONSTANT; e->lower[a] = e->upper[a] = 0.0f; }
+    e->gate[a] = bc == EUO_PERIODIC ? 2 : (bc == EUO_MIRROR || bc == EUO_REFLECT) ? 1 : 0;
+  }
+  euo_weight_matrix(degree, e->m);
+}
+
+/* map.h:268-279 */
+static float v_fmod(float lhs, float rhs)
+{
+  float help = lhs;
+  help /= rhs;
+  help = truncf(help);
+  help *= rhs;
+  lhs -= help;
+  if (fabsf(lhs) >= fabsf(rhs)) lhs = 0.0f;
+  return lhs;
+}
+
+static float gate(const ev_t *e, int a, float c)
+{
+  float lower = e->lower[a], upper = e->upper[a];
+  if (e->gate[a] == 2) {          /* map.h:423-440 */
+    float cc = c - lower;
+    float w = upper - lower;
+    int below = cc < 0.0f, above = cc >= w;
+    if (below || above) {
+      float cm = v_fmod(cc, w);
+      if (below) cm = cm + w;
+      if (cm >= w) cm = 0.0f;
+      cc = cm;
+    }
+    return cc + lower;
+  }
+  if (e->gate[a] == 1) {          /* map.h:341-357 */
+    float cc = c - lower;
+    float w = upper - lower;
+    cc = fabsf(cc);
+    if (cc >= w) {
+      float cm = v_fmod(cc, 2 * w);
+      cm -= w;
+      cm = fabsf(cm);
+      cm = w - cm;
+      cc = cm;
+    }
+    return cc + lower;
+  }
+  /* clamp, map.h:231-236 */
+  float r = c;
+  if (c < lower) r = lower;
+  if (c > upper) r = upper;
+  return r;
+}
+
+static void ev_eval(const ev_t *e, float cx, float cy, float *out)
+{
+  int d = e->degree, nch = e->nch, order = d + 1;
+  float g[2] = { gate(e, 0, cx), gate(e, 1, cy) };
+  float fl[2], tune[2];
+  int sel[2];
+  for (int a = 0; a < 2; a++) {
+    fl[a] = (d & 1) ? floorf(g[a]) : roundf(g[a]);
+    tune[a] = g[a] - fl[a];
+    sel[a] = (int)fl[a];
+  }
+  /* eval.h:1292-1294: int32 offset in float elements */
+  int origin = sel[0] * e->es[0];
+  origin += sel[1] * e->es[1];
+  const float *p = e->base + origin;
+  if (d == 0) {
+    for (int c = 0; c < nch; c++) out[c] = p[c];
+    return;
+  }
+  if (d == 1) {
+    float wl0 = 1.0f - tune[0], wr0 = tune[0];
+    float wl1 = 1.0f - tune[1], wr1 = tune[1];
+    for (int c = 0; c < nch; c++) {
+      float sum = p[c];
+      sum *= wl0;
+      sum += p[e->es[0] + c] * wr0;
+      sum *= wl1;
+      float sub = p[e->es[1] + c];
+      sub *= wl0;
+      sub += p[e->es[1] + e->es[0] + c] * wr0;
+      sum += sub * wr1;
+      out[c] = sum;
+    }
+    return;
+  }
+  float wx[EUO_MAX_DEGREE + 1], wy[EUO_MAX_DEGREE + 1];
+  weights_from_matrix(e->m, d, tune[0], wx);
+  weights_from_matrix(e->m, d, tune[1], wy);
+  int off0 = -(d / 2);
+  for (int c = 0; c < nch; c++) {
+    float sum = 0.0f;
+    for (int j = 0; j < order; j++) {
+      const float *row = p + (j + off0) * e->es[1] + off0 * e->es[0] + c;
+      float r = row[0];
+      r *= wx[0];
+      for (int i = 1; i < order; i++) r += wx[i] * row[i * e->es[0]];
+      if (j == 0) { sum = r; sum *= wy[0]; }
+      else sum += r * wy[j];
+    }
+    out[c] = sum;
+  }
+}
+
+void euo_eval(const euo_spline *s, const float *crd, long n, float *out)
+{
+  ev_t e;
+  ev_init(&e, s, s->degree);
+  for (long i = 0; i < n; i++)
+    ev_eval(&e, crd[2 * i], crd[2 * i + 1], out + i * s->nch);
+}
+
+void euo_eval_shifted(const euo_spline *s, int degree, const float *crd, long n,
+                      float *out)
+{
+  ev_t e;
+  ev_init(&e, s, degree);
+  for (long i = 0; i < n; i++)
+    ev_eval(&e, crd[2 * i], crd[2 * i + 1], out + i * s->nch);
+}
+
+/* ------------------------------------------------------------------------ */
+/* geometry.h:1178-1289 cube face + in-face coordinate                       */
+/* ------------------------------------------------------------------------ */
+
+static void ray_to_cubeface(const float *c, int *face, float *in_face)
+{
+  float ax = fabsf(c[0]), ay = fabsf(c[1]), az = fabsf(c[2]);
+  int m1 = ax >= ay, m2 = ax >= az, m3 = ay >= az;
+  if (m1 && m2) {
+    *face = c[0] < 0.0f ? 0 : 1;          /* CM_LEFT : CM_RIGHT */
+    in_face[0] = -c[2] / c[0];
+    in_face[1] = c[1] / ax;
+  } else if (!m2 && !m3) {
+    *face = c[2] < 0.0f ? 5 : 4;          /* CM_BACK : CM_FRONT */
+    in_face[0] = c[0] / c[2];
+    in_face[1] = c[1] / az;
+  } else {
+    *face = c[1] < 0.0f ? 2 : 3;          /* CM_TOP : CM_BOTTOM */
+    in_face[0] = -c[0] / ay;
+    in_face[1] = c[2] / c[1];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* cubemap source set-up (cubemap.h:233-400, :576-946, :1143-1233)           */
+/* ------------------------------------------------------------------------ */
+
+void euo_metrics_init(euo_metrics *m, long face_px, double face_fov,
+                      long support_min_px, long tile_px)
+{
+  double overscan_md = 0.0, diameter_md = 2.0;
+  m->face_px = face_px;
+  m->radius_md = 1.0;
+  m->inherent_support_px = 0;
+  if (face_fov > M_PI_2) {
+    m->radius_md = tan(face_fov / 2.0);
+    diameter_md = 2.0 * m->radius_md;
+    overscan_md = m->radius_md - 1.0;
+  }
+  m->model_to_px = (double)face_px / diameter_md;
+  m->px_to_model = diameter_md / (double)face_px;
+  double px_overscan = m->model_to_px * overscan_md;
+  m->inherent_support_px = (long)trunc(px_overscan);
+  m->discrete90 = (px_overscan - trunc(px_overscan) < 0.0000001);
+  long additional = 0;
+  if (m->inherent_support_px < support_min_px)
+    additional = support_min_px - m->inherent_support_px;
+  long px_min = face_px + 2 * additional;
+  m->n_tiles = px_min / tile_px;
+  if (m->n_tiles * tile_px < px_min) m->n_tiles++;
+  m->section_px = m->n_tiles * tile_px;
+  long frame_total = m->section_px - face_px;
+  m->left_frame_px = frame_total / 2;
+  m->right_frame_px = frame_total - m->left_frame_px;
+  m->section_md = m->px_to_model * m->section_px;
+  double refc_px = (double)m->left_frame_px + (double)face_px / 2.0;
+  m->refc_md = m->px_to_model * refc_px;
+}
+
+/* cubemap.h:724-809 for one frame pixel; crd2 are the doubled integer
+ * coordinates of linspace_t<int>(-(section_px-1), 2) */
+static void fill_frame_px(const euo_metrics *m, const ev_t *bil, int face,
+                          int ix, int iy, int ithird, float *px)
+{
+  float c3[3];
+  switch (face) {
+    case 4: c3[0] = (float)ix;  c3[1] = (float)iy; c3[2] = (float)ithird; break;
+    case 5: c3[0] = (float)-ix; c3[1] = (float)iy; c3[2] = (float)-ithird; break;
+    case 1: c3[0] = (float)ithird;  c3[1] = (float)iy; c3[2] = (float)-ix; break;
+    case 0: c3[0] = (float)-ithird; c3[1] = (float)iy; c3[2] = (float)ix; break;
+    case 3: c3[0] = (float)-ix; c3[1] = (float)ithird;  c3[2] = (float)iy; break;
+    default: c3[0] = (float)-ix; c3[1] = (float)-ithird; c3[2] = (float)-iy; break;
+  }
+  int fv;
+  float inf[2], pick[2];
+  ray_to_cubeface(c3, &fv, inf);
+  /* metrics_t::get_pickup_coordinate_px, cubemap.h:452-464: the sum is
+   * formed in double (A.0), the compound operations narrow their operand */
+  pick[0] = (float)((double)inf[0] + m->refc_md);
+  pick[1] = (float)((double)inf[1] + m->refc_md);
+  pick[0] *= (float)m->model_to_px;
+  pick[1] *= (float)m->model_to_px;
+  pick[1] += (float)(fv * (int)m->section_px);
+  pick[0] -= .5f;
+  pick[1] -= .5f;
+  ev_eval(bil, pick[0], pick[1], px);
+}
+
+void euo_cubemap_build(const euo_metrics *m, const float *faces, int nch,
+                       int spline_degree, int prefilter_degree, float *ir)
+{
+  long S = m->section_px, F = m->face_px, lf = m->left_frame_px, rf = m->right_frame_px;
+  (void)spline_degree;
+  euo_spline s;
+  memset(&s, 0, sizeof s);
+  s.data = ir; s.shape[0] = S; s.shape[1] = 6 * S; s.stride[0] = 1; s.stride[1] = S;
+  s.core[0] = S; s.core[1] = 6 * S; s.bc[0] = s.bc[1] = EUO_REFLECT;
+  s.degree = 1; s.nch = nch;
+  /* faces into their slots (cubemap.h:1147-1151, :1219) */
+  for (int f = 0; f < 6; f++)
+    for (long y = 0; y < F; y++)
+      memcpy(ir + (((f * S) + lf + y) * S + lf) * nch,
+             faces + ((f * F + y) * F) * nch, sizeof(float) * F * nch);
+  if (lf || rf) {
+    /* mirror_around, cubemap.h:607-659 */
+    for (int f = 0; f < 6; f++) {
+      float *cf = ir + ((f * S + lf) * S + lf) * nch;
+#define CF(x, y) (cf + ((long)(y) * S + (long)(x)) * nch)
+      int cmin = lf > 0 ? -1 : 0;
+      int cmax = rf > 0 ? (int)F : (int)F - 1;
+      for (int x = cmin; x <= cmax; x++) {
+        if (lf) memcpy(CF(x, -1), CF(x, 0), sizeof(float) * nch);
+        if (rf) memcpy(CF(x, F), CF(x, F - 1), sizeof(float) * nch);
+      }
+      for (int y = cmin; y <= cmax; y++) {
+        if (lf) memcpy(CF(-1, y), CF(0, y), sizeof(float) * nch);
+        if (rf) memcpy(CF(F, y), CF(F - 1, y), sizeof(float) * nch);
+      }
+#undef CF
+    }
+    /* fill_support, cubemap.h:819-911 */
+    ev_t bil;
+    ev_init(&bil, &s, 1);
+    int ithird = (int)(m->model_to_px * 2);
+    int ishift = (int)S - 1;
+    for (int f = 0; f < 6; f++) {
+      float *sec = ir + (f * S) * S * nch;
+      long win[4][4] = {
+        { 0, 0, S, lf },
+        { 0, S - rf, S, S },
+        { 0, lf, lf, S - rf },
+        { lf + F, lf, S, S - rf } };
+      int on[4] = { lf > 0, rf > 0, lf > 0, rf > 0 };
+      for (int k = 0; k < 4; k++) {
+        if (!on[k]) continue;
+#pragma omp parallel for schedule(static)
+        for (long y = win[k][1]; y < win[k][3]; y++)
+          for (long x = win[k][0]; x < win[k][2]; x++)
+            fill_frame_px(m, &bil, f, (int)(2 * x - ishift), (int)(2 * y - ishift),
+                          ithird, sec + (y * S + x) * nch);
+      }
+    }
+  }
+  /* per-face prefilter, NATURAL x NATURAL, float epsilon (cubemap.h:921-946) */
+  if (prefilter_degree > 1) {
+    for (int f = 0; f < 6; f++) {
+      float *sec = ir + (f * S) * S * nch;
+      for (int c = 0; c < nch; c++)
+        euo_filter_lines(sec + c, S, S * nch, S, nch, EUO_NATURAL,
+                         prefilter_degree, FLT_EPSILON);
+      for (int c = 0; c < nch; c++)
+        euo_filter_lines(sec + c, S, nch, S, S * nch, EUO_NATURAL,
+                         prefilter_degree, FLT_EPSILON);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* steppers (stepper.h) - one instance per row segment                       */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  int projection, normalize;
+  int width, height;
+  float fx0, fx1, fy0, fy1, bias_x, bias_y, delta;
+  float xx[3], yy[3], zz[3];
+  float section_md, refc_md;     /* cubemap/biatan6 */
+} stepper_t;
+
+/* stepper.h:294-307 */
+static void stepper_init(stepper_t *s, int projection, int normalize,
+                         const double *basis9, int width, int height,
+                         double a0d, double a1d, double b0d, double b1d,
+                         float bias_x, float bias_y)
+{
+  float a0 = (float)a0d, a1 = (float)a1d, b0 = (float)b0d, b1 = (float)b1d;
+  s->projection = projection;
+  s->normalize = normalize;
+  s->width = width;
+  s->height = height;
+  s->fx1 = (float)(a1 / (2.0 * width));
+  s->fx0 = (float)(a0 / (2.0 * width));
+  s->fy1 = (float)(b1 / (2.0 * height));
+  s->fy0 = (float)(b0 / (2.0 * height));
+  s->bias_x = bias_x * (a1 - a0) / (float)width;
+  s->bias_y = bias_y * (b1 - b0) / (float)height;
+  s->delta = (float)EUO_LANES * (a1 - a0) / (float)width;
+  for (int i = 0; i < 3; i++) {
+    s->xx[i] = (float)basis9[i];
+    s->yy[i] = (float)basis9[3 + i];
+    s->zz[i] = (float)basis9[6 + i];
+  }
+  s->section_md = a1 - a0;
+  s->refc_md = (float)((a1 - a0) / 2.0);
+}
+
+/* planar coordinate of pixel (x, y): stepper.h:324-350. The x value is the
+ * segment-start value of the pixel's lane plus k additions of delta. */
+static void planar_at(const stepper_t *s, int x, int y, float *p)
+{
+  int seg_start = (x / EUO_SEGMENT) * EUO_SEGMENT;
+  int in_seg = x - seg_start;
+  int lane = in_seg % EUO_LANES, k = in_seg / EUO_LANES;
+  float ll0 = (float)(2 * lane) + (float)(seg_start * 2 + 1);
+  float p0 = s->bias_x + ll0 * s->fx1 + ((float)(2 * s->width) - ll0) * s->fx0;
+  for (int i = 0; i < k; i++) p0 += s->delta;
+  int ll1 = y * 2 + 1;
+  float p1 = s->bias_y + ll1 * s->fy1 + (float)(2 * s->height - ll1) * s->fy0;
+  p[0] = p0;
+  p[1] = p1;
+}
+
+static void normalize3(float *t)
+{
+  /* xel.h:752-765: sqn = v0*v0; sqn += v1*v1; sqn += v2*v2 */
+  float sqn = t[0] * t[0];
+  sqn += t[1] * t[1];
+  sqn += t[2] * t[2];
+  float n = sqrtf(sqn);
+  t[0] /= n; t[1] /= n; t[2] /= n;
+}
+
+/* ray for pixel (x,y) */
+static void stepper_ray(const stepper_t *s, int x, int y, float *trg)
+{
+  float pl[2];
+  planar_at(s, x, y, pl);
+  const float *xx = s->xx, *yy = s->yy, *zz = s->zz;
+  switch (s->projection) {
+    case EUO_SPHERICAL: {       /* stepper.h:605-667 */
+      float sy = sinf(pl[1]), r = cosf(pl[1]);
+      float sx = sinf(pl[0]), z = cosf(pl[0]);
+      for (int i = 0; i < 3; i++) {
+        float xxx = xx[i] * r, yyy = yy[i] * sy, zzz = zz[i] * r;
+        trg[i] = xxx * sx + zzz * z + yyy;
+      }
+      break;
+    }
+    case EUO_CYLINDRICAL: {     /* stepper.h:760-800 */
+      float sx = sinf(pl[0]), z = cosf(pl[0]);
+      /* the reciprocal length is taken once, from the first vector of the
+       * segment, and reused (stepper.h:771-775, :786) */
+      for (int i = 0; i < 3; i++) {
+        float yyy = yy[i] * pl[1];
+        trg[i] = xx[i] * sx + zz[i] * z + yyy;
+      }
+      if (s->normalize) {
+        /* rcp_length is a per-lane value computed at init() from that
+         * lane's first pixel in the segment */
+        int seg_start = (x / EUO_SEGMENT) * EUO_SEGMENT;
+        int lane = (x - seg_start) % EUO_LANES;
+        float p0[2], t0[3];
+        planar_at(s, seg_start + lane, y, p0);
+        float sx0 = sinf(p0[0]), z0 = cosf(p0[0]);
+        for (int i = 0; i < 3; i++) {
+          float yyy = yy[i] * p0[1];
+          t0[i] = xx[i] * sx0 + zz[i] * z0 + yyy;
+        }
+        float sqn = t0[0] * t0[0];
+        sqn += t0[1] * t0[1];
+        sqn += t0[2] * t0[2];
+        float rcp = 1.0f / sqrtf(sqn);
+        trg[0] *= rcp; trg[1] *= rcp; trg[2] *= rcp;
+      }
+      break;
+    }
+    case EUO_RECTILINEAR: {     /* stepper.h:895-932 */
+      for (int i = 0; i < 3; i++) {
+        float ddd = yy[i] * pl[1] + zz[i];
+        trg[i] = xx[i] * pl[0] + ddd;
+      }
+      if (s->normalize) normalize3(trg);
+      break;
+    }
+    case EUO_FISHEYE:
+    case EUO_STEREOGRAPHIC: {   /* stepper.h:1019-1030, :1146-1157 */
+      float sqn = pl[0] * pl[0];
+      sqn += pl[1] * pl[1];
+      float nrm = sqrtf(sqn);
+      double ad;
+      if (s->projection == EUO_FISHEYE)
+        ad = M_PI_2 - (double)nrm;
+      else
+        ad = M_PI_2 - 2.0 * atan((double)nrm / 2.0);
+      /* sincos(vec<double>, vec<float>&, vec<float>&) resolves to the float
+       * overload: the angle narrows to float first */
+      float a = (float)ad;
+      float b = atan2f(pl[0], pl[1]);
+      float z = sinf(a), r = cosf(a);
+      float sx = sinf(b), sy = cosf(b);
+      for (int i = 0; i < 3; i++)
+        trg[i] = xx[i] * r * sx + zz[i] * z + yy[i] * r * sy;
+      break;
+    }
+    case EUO_CUBEMAP:
+    case EUO_BIATAN6: {         /* stepper.h:1274-1358, :1449-1560 */
+      int face = y / s->width;
+      float p1 = pl[1] + (float)(3 - face) * s->section_md - s->refc_md;
+      float p0 = pl[0];
+      if (s->projection == EUO_BIATAN6) {
+        p1 = tanf(p1 * (float)(M_PI / 4.0));
+        p0 = tanf(p0 * (float)(M_PI / 4.0));
+      }
+      float ccc[3], vvv[3];
+      for (int i = 0; i < 3; i++) {
+        switch (face) {
+          case 0: ccc[i] = (float)(-1.0 * (double)xx[i] + (double)(p1 * yy[i])); vvv[i] = zz[i]; break;
+          case 1: ccc[i] = (float)(1.0 * (double)xx[i] + (double)(p1 * yy[i])); vvv[i] = -zz[i]; break;
+          case 2: ccc[i] = (float)(-1.0 * (double)yy[i] - (double)(p1 * zz[i])); vvv[i] = -xx[i]; break;
+          case 3: ccc[i] = (float)(1.0 * (double)yy[i] + (double)(p1 * zz[i])); vvv[i] = -xx[i]; break;
+          case 4: ccc[i] = (float)((double)(p1 * yy[i]) + 1.0 * (double)zz[i]); vvv[i] = xx[i]; break;
+          default: ccc[i] = (float)((double)(p1 * yy[i]) - 1.0 * (double)zz[i]); vvv[i] = -xx[i]; break;
+        }
+        trg[i] = ccc[i] + p0 * vvv[i];
+      }
+      if (s->normalize) normalize3(trg);
+      break;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* source lookup: mount_t / source_t / cubemap_view_t (environment.h)        */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  const euo_source *src;
+  ev_t ev;
+  double tex[4], wex[4];       /* total_extent, window_extent */
+  float wexf[4];               /* window extent narrowed for the compares */
+  float brighten;
+} mount_t;
+
+static void mount_init(mount_t *m, const euo_source *src)
+{
+  m->src = src;
+  ev_init(&m->ev, &src->spl, src->spl.degree);
+  m->brighten = (float)src->brighten;
+  if (src->projection == EUO_CUBEMAP || src->projection == EUO_BIATAN6) return;
+  /* environment.h:617-633 (the y terms divide by total_width and add
+   * window_width, as the reference does) */
+  euo_get_extent(src->projection, src->width, src->height, src->hfov, m->tex);
+  double wx = m->tex[1] - m->tex[0];
+  double wy = m->tex[3] - m->tex[2];
+  double px = (double)src->window_x_offset / src->width;
+  double py = (double)src->window_y_offset / src->width;
+  m->wex[0] = m->tex[0] + px * wx;
+  m->wex[2] = m->tex[2] + py * wy;
+  px = (double)(src->window_x_offset + src->window_width) / src->width;
+  py = (double)(src->window_y_offset + src->window_width) / src->width;
+  m->wex[1] = m->tex[0] + px * wx;
+  m->wex[3] = m->tex[2] + py * wy;
+  for (int i = 0; i < 4; i++) m->wexf[i] = (float)m->wex[i];
+}
+
+/* ray -> source planar coordinate, geometry.h:278-540 */
+static void ray_to_planar(int projection, const float *ray, float *crd)
+{
+  float right = ray[0], down = ray[1], forward = ray[2];
+  switch (projection) {
+    case EUO_SPHERICAL: {
+      float s = sqrtf(right * right + forward * forward);
+      crd[1] = atan2f(down, s);
+      crd[0] = atan2f(right, forward);
+      break;
+    }
+    case EUO_CYLINDRICAL: {
+      float s = sqrtf(right * right + forward * forward);
+      crd[1] = down / s;
+      crd[0] = atan2f(right, forward);
+      break;
+    }
+    case EUO_RECTILINEAR:
+      crd[0] = right / forward;
+      crd[1] = down / forward;
+      break;
+    case EUO_STEREOGRAPHIC: {
+      float rn = 1.0f / sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+      float r = right * rn, d = down * rn, f = forward * rn;
+      float factor = 2.0f / (f + 1.0f);
+      crd[0] = r * factor;
+      crd[1] = d * factor;
+      break;
+    }
+    case EUO_FISHEYE: {
+      float s = sqrtf(right * right + down * down);
+      float r = (float)M_PI_2 - atan2f(forward, s);
+      float phi = atan2f(down, right);
+      crd[0] = r * cosf(phi);
+      crd[1] = r * sinf(phi);
+      break;
+    }
+  }
+}
+
+/* pto_planar forward direction, environment.h:240-340 + lens_correction.h */
+static void planar_lens(const euo_source *src, float *crd);
+
+/* returns the hit mask; px gets nch floats */
+static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
+{
+  const euo_source *src = m->src;
+  int nch = src->spl.nch;
+  if (src->projection == EUO_CUBEMAP || src->projection == EUO_BIATAN6) {
+    int face;
+    float inf[2], pick[2];
+    ray_to_cubeface(ray, &face, inf);
+    if (src->projection == EUO_BIATAN6) {
+      inf[0] = (float)(4.0 / M_PI) * atanf(inf[0]);
+      inf[1] = (float)(4.0 / M_PI) * atanf(inf[1]);
+    }
+    /* environment.h:1452-1460 */
+    pick[0] = inf[0] + src->refc_md;
+    pick[1] = inf[1] + src->refc_md;
+    pick[0] *= src->model_to_px;
+    pick[1] *= src->model_to_px;
+    pick[1] += (float)(face * src->section_px);
+    pick[0] -= .5f;
+    pick[1] -= .5f;
+    if (dbg) { dbg[0] = pick[0]; dbg[1] = pick[1]; dbg[2] = (float)face; }
+    ev_eval(&m->ev, pick[0], pick[1], px);
+    return 1;
+  }
+  float crd[2] = { 0.0f, 0.0f };
+  ray_to_planar(src->projection, ray, crd);
+  if (src->has_lcp) planar_lens(src, crd);
+  /* source_t::test_crd, environment.h:970-977: float compares */
+  int mask = crd[0] >= m->wexf[0] && crd[0] <= m->wexf[1]
+          && crd[1] >= m->wexf[2] && crd[1] <= m->wexf[3];
+  if (src->projection == EUO_RECTILINEAR) mask = mask && (ray[2] > 0.0f);
+  if (!mask) {
+    for (int c = 0; c < nch; c++) px[c] = 0.0f;
+    if (dbg) { dbg[0] = dbg[1] = 0.0f; dbg[2] = -1.0f; }
+    return 0;
+  }
+  /* md_to_spline, environment.h:988-1006 */
+  float ic0 = (float)((double)crd[0] - m->tex[0]);
+  ic0 /= (float)(m->tex[1] - m->tex[0]);
+  ic0 *= (float)src->width;
+  ic0 -= .5f;
+  float ic1 = (float)((double)crd[1] - m->tex[2]);
+  ic1 /= (float)(m->tex[3] - m->tex[2]);
+  ic1 *= (float)src->height;
+  ic1 -= .5f;
+  float s0 = ic0 - (float)src->window_x_offset;
+  float s1 = ic1 - (float)src->window_y_offset;
+  if (dbg) { dbg[0] = s0; dbg[1] = s1; dbg[2] = 0.0f; }
+  ev_eval(&m->ev, s0, s1, px);
+  return 1;
+}
+
+/* environment::eval brighten, environment.h:1821-1842 */
+static void brighten_px(const mount_t *m, float *px)
+{
+  int nch = m->src->spl.nch;
+  if (m->brighten != 1.0f) {
+    int ncol = (nch == 2 || nch == 4) ? nch - 1 : nch;
+    for (int c = 0; c < ncol; c++) px[c] *= m->brighten;
+  }
+}
+
+/* lens polynomial + shift + shear, PTO forward direction
+ * (environment.h:254-284; lens_correction.h:93-105, :224-235) */
+static void planar_lens(const euo_source *src, float *crd)
+{
+  /* restated when configuration 5 (multi-facet PTO) is built */
+  (void)src; (void)crd;
+}
+
+/* ------------------------------------------------------------------------ */
+/* the hot loop: zimt::process(shape, stepper, environment | twine_t, storer) */
+/* (envutil_payload.cc:425-579, :2118-2232; zimt/wielding.h:151-463;         */
+/*  twining.h:128-263)                                                       */
+/* ------------------------------------------------------------------------ */
+
+int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
+               float *out, long ors)
+{
+  if (nsrc != 1) return -2;     /* multi-facet synopsis: next row */
+  const euo_source *src = &srcs[0];
+  int nch = job->nch;
+  if (src->spl.nch != nch) return -3;
+  double r_cam[9], r_fct[9], basis[9];
+  euo_make_r3(job->roll, job->pitch, job->yaw, 0, r_cam);
+  euo_make_r3(src->roll, src->pitch, src->yaw, 1, r_fct);
+  euo_rotate_r3(r_cam, r_fct, basis);
+  int twining = job->ntaps > 0;
+  stepper_t st00, st10, st01;
+  /* single facet, no twining: normalize = false (payload.cc:2118);
+   * deriv_stepper: normalize = true, bias .25 (payload.cc:2227, stepper.h:1617) */
+  stepper_init(&st00, job->projection, twining, basis, job->width, job->height,
+               job->x0, job->x1, job->y0, job->y1, 0.0f, 0.0f);
+  stepper_init(&st10, job->projection, 1, basis, job->width, job->height,
+               job->x0, job->x1, job->y0, job->y1, 0.25f, 0.0f);
+  stepper_init(&st01, job->projection, 1, basis, job->width, job->height,
+               job->x0, job->x1, job->y0, job->y1, 0.0f, 0.25f);
+  mount_t mnt;
+  mount_init(&mnt, src);
+  /* twine_t ctor: x and y of every tap pre-multiplied by 4 (twining.h:106-121) */
+  float *taps = NULL;
+  if (twining) {
+    taps = (float *)malloc(sizeof(float) * 3 * (size_t)job->ntaps);
+    for (int k = 0; k < job->ntaps; k++) {
+      taps[3 * k + 0] = job->taps[3 * k + 0] * 4.0f;
+      taps[3 * k + 1] = job->taps[3 * k + 1] * 4.0f;
+      taps[3 * k + 2] = job->taps[3 * k + 2];
+    }
+  }
+  int nthreads = job->nthreads > 0 ? job->nthreads : 1;
+  int W = job->width;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+  for (int y = job->row_begin; y < job->row_end; y++) {
+    float *row = out + (long)(y - job->row_begin) * ors;
+    for (int x = 0; x < W; x++) {
+      float ray[3], px[4], dbg[3];
+      stepper_ray(&st00, x, y, ray);
+      if (job->stage == 1) {
+        row[3 * x] = ray[0]; row[3 * x + 1] = ray[1]; row[3 * x + 2] = ray[2];
+        continue;
+      }
+      if (!twining) {
+        mount_eval(&mnt, ray, px, dbg);
+        if (job->stage == 2) {
+          row[3 * x] = dbg[0]; row[3 * x + 1] = dbg[1]; row[3 * x + 2] = dbg[2];
+          continue;
+        }
+        brighten_px(&mnt, px);
+        for (int c = 0; c < nch; c++) row[(long)x * nch + c] = px[c];
+      } else {
+        float r10[3], r01[3], dx[3], dy[3], acc[4] = { 0, 0, 0, 0 };
+        stepper_ray(&st10, x, y, r10);
+        stepper_ray(&st01, x, y, r01);
+        for (int i = 0; i < 3; i++) { dx[i] = r10[i] - ray[i]; dy[i] = r01[i] - ray[i]; }
+        for (int k = 0; k < job->ntaps; k++) {
+          float in_k[3];
+          for (int i = 0; i < 3; i++)
+            in_k[i] = ray[i] + taps[3 * k] * dx[i] + taps[3 * k + 1] * dy[i];
+          mount_eval(&mnt, in_k, px, NULL);
+          brighten_px(&mnt, px);
+          for (int c = 0; c < nch; c++) acc[c] += taps[3 * k + 2] * px[c];
+        }
+        for (int c = 0; c < nch; c++) row[(long)x * nch + c] = acc[c];
+      }
+    }
+  }
+  free(taps);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* double-precision projection functors for the reference's own property     */
+/* tests (geometry.h:152-560; geometry.cc:283-420)                           */
+/* ------------------------------------------------------------------------ */
+
+void euo_prj_to_ray_d(int projection, const double *in, double *out)
+{
+  switch (projection) {
+    case EUO_SPHERICAL: {
+      double sl = sin(in[1]), cl = cos(in[1]), so = sin(in[0]), co = cos(in[0]);
+      out[0] = so * cl; out[2] = co * cl; out[1] = sl;
+      break;
+    }
+    case EUO_CYLINDRICAL:
+      out[2] = cos(in[0]); out[0] = sin(in[0]); out[1] = in[1];
+      break;
+    case EUO_RECTILINEAR:
+      out[0] = in[0]; out[1] = in[1]; out[2] = 1.0;
+      break;
+    case EUO_STEREOGRAPHIC: {
+      double r = sqrt(in[0] * in[0] + in[1] * in[1]);
+      double theta = atan(r / 2.0) * 2.0;
+      double phi = atan2(in[0], -in[1]);
+      out[2] = cos(theta);
+      out[1] = -sin(theta) * cos(phi);
+      out[0] = sin(theta) * sin(phi);
+      break;
+    }
+    case EUO_FISHEYE: {
+      double r = sqrt(in[0] * in[0] + in[1] * in[1]);
+      double phi = atan2(in[0], -in[1]);
+      out[2] = cos(r);
+      out[1] = -sin(r) * cos(phi);
+      out[0] = sin(r) * sin(phi);
+      break;
+    }
+  }
+}
+
+void euo_ray_to_prj_d(int projection, const double *in, double *out)
+{
+  double right = in[0], down = in[1], forward = in[2];
+  switch (projection) {
+    case EUO_SPHERICAL: {
+      double s = sqrt(right * right + forward * forward);
+      out[1] = atan2(down, s); out[0] = atan2(right, forward);
+      break;
+    }
+    case EUO_CYLINDRICAL: {
+      double s = sqrt(right * right + forward * forward);
+      out[1] = down / s; out[0] = atan2(right, forward);
+      break;
+    }
+    case EUO_RECTILINEAR:
+      out[0] = right / forward; out[1] = down / forward;
+      break;
+    case EUO_STEREOGRAPHIC: {
+      double rn = 1.0 / sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]);
+      double r = right * rn, d = down * rn, f = forward * rn;
+      double factor = 2.0 / (f + 1.0);
+      out[0] = r * factor; out[1] = d * factor;
+      break;
+    }
+    case EUO_FISHEYE: {
+      double s = sqrt(right * right + down * down);
+      double r = M_PI_2 - atan2(forward, s);
+      double phi = atan2(down, right);
+      out[0] = r * cos(phi); out[1] = r * sin(phi);
+      break;
+    }
+  }
+}

@@ -1,0 +1,246 @@
+// TEST INFRASTRUCTURE - not product code.
+//
+// Thin C-ABI harness around the reference's own zimt headers, compiled IN PLACE
+// from /root/reference (see oracle/Makefile, target _ref/libref_zimt.so). Nothing
+// from the reference is copied here: this file only *calls* zimt's public
+// templates so that the plain-C restatement in oracle/eu_oracle.c can be
+// checked bit-for-bit against the reference implementation of
+//   * b-spline container layout + bracing   (zimt/bspline.h, zimt/brace.h)
+//   * recursive prefilter                   (zimt/prefilter.h, recursive.h, filter.h)
+//   * gates + split + weights + weighted sum (zimt/map.h, basis.h, eval.h)
+//   * the strip-mining driver               (zimt/wielding.h, get.h, put.h)
+// Back-end: zimt "goading" (no USE_HWY/USE_VC/USE_STDSIMD), LANES = 16,
+// segment 512, compiled with -ffp-contract=off: the pinned oracle definition
+// of SURVEY.md §8(c).
+//
+// envutil's own headers (geometry.h, stepper.h, environment.h, cubemap.h,
+// twining.h) cannot be compiled here: every one of them reaches
+// envutil_basic.h:198-200, which includes OpenImageIO (absent from the image).
+// Those stages are restated from the source text and are NOT pinned by this
+// library ("Oracle").
+
+#include <cstring>
+#include <vector>
+#include <memory>
+#include "zimt/zimt.h"
+#include "zimt/bspline.h"
+#include "zimt/prefilter.h"
+#include "zimt/eval.h"
+
+namespace {
+
+static const std::size_t L = zimt::simd_traits<float>::default_size;
+
+struct handle_base {
+  int nch;
+  virtual ~handle_base() {}
+  virtual void prefilter(int prefilter_degree) = 0;
+  virtual void spherical(int prefilter_degree) = 0;
+  virtual void brace(int axis) = 0;
+  virtual void geometry(long *out) = 0;
+  virtual float *container_data() = 0;
+  virtual void eval(const float *crd, long n, float *out) = 0;
+  virtual void process_affine(long w, long h, const float *aff, float *out) = 0;
+};
+
+template <int NCH>
+struct handle : handle_base {
+  typedef zimt::xel_t<float, NCH> px_t;
+  typedef zimt::bspline<px_t, 2> spl_t;
+  typedef zimt::xel_t<float, 2> crd_t;
+  typedef zimt::simdized_type<crd_t, L> crd_v;
+  typedef zimt::simdized_type<px_t, L> px_v;
+  std::unique_ptr<spl_t> sp;
+
+  handle(const float *core, long W, long H, int degree, int bc0, int bc1) {
+    nch = NCH;
+    sp.reset(new spl_t({std::size_t(W), std::size_t(H)}, degree,
+                       {zimt::bc_code(bc0), zimt::bc_code(bc1)}));
+    for (long y = 0; y < H; y++)
+      for (long x = 0; x < W; x++) {
+        px_t p;
+        for (int c = 0; c < NCH; c++) p[c] = core[(y * W + x) * NCH + c];
+        sp->core[{x, y}] = p;
+      }
+  }
+
+  // source_t's ordinary branch: the spline is filtered with prefilter_degree but
+  // keeps the frame it was allocated with (environment.h:933-936)
+  void prefilter(int prefilter_degree) override {
+    int keep = sp->spline_degree;
+    sp->spline_degree = prefilter_degree;
+    sp->prefilter();
+    sp->spline_degree = keep;
+  }
+
+  // The sequence of zimt calls envutil makes for a full 360x180 degree lat/lon
+  // image (environment.h:356-522): periodic rows, then every left-half column
+  // stacked on the flipped opposite column as ONE periodic line, tolerance 1e-4,
+  // over-the-pole frame rows, periodic brace along x.
+  void spherical(int prefilter_degree) override {
+    typedef zimt::view_t<2, px_t> view_type;
+    typedef zimt::recursive_filter<zimt::simdized_type, float> stripe_t;
+    int degree = prefilter_degree;
+    auto out = sp->core;
+    zimt::iir_filter_specs specs(zimt::PERIODIC, degree / 2,
+                                 zimt_constants::precomputed_poles[degree],
+                                 0.0001);
+    if (degree > 1)
+      zimt::detail::separable_filter<view_type, view_type, stripe_t>()
+        (out, out, 0, specs);
+    auto shape = out.shape;
+    shape[0] /= 2;
+    auto neg = out.strides;
+    neg[1] = -neg[1];
+    view_type upper(shape, out.strides, out.data());
+    view_type lower(shape, neg,
+                    out.data() + (shape[1] - 1) * out.strides[1]
+                               + shape[0] * out.strides[0]);
+    std::vector<view_type> stack{upper, lower};
+    if (degree > 1)
+      zimt::detail::separable_filter<view_type, view_type, stripe_t>()
+        (stack, stack, 1, specs, zimt::default_njobs);
+    view_type left(shape, out.strides, out.data());
+    view_type right(shape, out.strides, out.data() + shape[0]);
+    long H = shape[1];
+    for (long k = 0; k < long(sp->left_frame[1]); k++) {
+      left.slice(1, -1 - k).copy_data(right.slice(1, k));
+      right.slice(1, -1 - k).copy_data(left.slice(1, k));
+    }
+    for (long k = 0; k < long(sp->right_frame[1]); k++) {
+      left.slice(1, H + k).copy_data(right.slice(1, H - 1 - k));
+      right.slice(1, H + k).copy_data(left.slice(1, H - 1 - k));
+    }
+    sp->brace(0);
+  }
+
+  void brace(int axis) override { sp->brace(axis); }
+
+  void geometry(long *o) override {
+    o[0] = sp->container.shape[0];
+    o[1] = sp->container.shape[1];
+    o[2] = sp->container.strides[0];
+    o[3] = sp->container.strides[1];
+    o[4] = sp->left_frame[0];
+    o[5] = sp->left_frame[1];
+    o[6] = sp->right_frame[0];
+    o[7] = sp->right_frame[1];
+    o[8] = sp->core.shape[0];
+    o[9] = sp->core.shape[1];
+  }
+
+  float *container_data() override { return (float *)sp->container.data(); }
+
+  void eval(const float *crd, long n, float *out) override {
+    auto ev = zimt::make_safe_evaluator<spl_t, float, L>(*sp);
+    for (long i0 = 0; i0 < n; i0 += L) {
+      crd_v c;
+      px_v p;
+      for (std::size_t l = 0; l < L; l++) {
+        long i = i0 + l < n ? i0 + l : n - 1;
+        c[0][l] = crd[2 * i];
+        c[1][l] = crd[2 * i + 1];
+      }
+      ev.eval(c, p);
+      for (std::size_t l = 0; l < L && i0 + long(l) < n; l++)
+        for (int ch = 0; ch < NCH; ch++) out[(i0 + l) * NCH + ch] = p[ch][l];
+    }
+  }
+
+  // zimt::process over a w x h raster: discrete coordinate -> affine map
+  // (x' = a0 + a1*x, y' = a2 + a3*y) -> safe evaluator -> storer. Exercises
+  // the driver's segmentation and the leftover ("cap") paths.
+  struct affine_t : public zimt::unary_functor<zimt::xel_t<float, 2>, crd_t, L> {
+    float a[4];
+    template <typename I, typename O>
+    void eval(const I &in, O &out) const {
+      out[0] = in[0] * a[1] + a[0];
+      out[1] = in[1] * a[3] + a[2];
+    }
+  };
+
+  void process_affine(long w, long h, const float *aff, float *out) override {
+    auto ev = zimt::make_safe_evaluator<spl_t, float, L>(*sp);
+    affine_t af;
+    for (int i = 0; i < 4; i++) af.a[i] = aff[i];
+    zimt::view_t<2, px_t> trg((px_t *)out, {1L, w},
+                              {std::size_t(w), std::size_t(h)});
+    zimt::storer<float, NCH, 2, L> st(trg);
+    zimt::get_crd<float, 2, 2, L> gc;
+    zimt::process(trg.shape, gc, af + ev, st);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ref_lanes() { return int(L); }
+int ref_segment() { return int(zimt::bill_t().segment_size); }
+
+// bc codes are passed as zimt numbers them (zimt/common.h:82-91):
+// MIRROR 0, PERIODIC 1, REFLECT 2, NATURAL 3, CONSTANT 4, ZEROPAD 5, GUESS 6
+
+void *ref_bspline_new(const float *core, long W, long H, int nch, int degree,
+                      int bc0, int bc1) {
+  switch (nch) {
+    case 1: return new handle<1>(core, W, H, degree, bc0, bc1);
+    case 2: return new handle<2>(core, W, H, degree, bc0, bc1);
+    case 3: return new handle<3>(core, W, H, degree, bc0, bc1);
+    case 4: return new handle<4>(core, W, H, degree, bc0, bc1);
+  }
+  return nullptr;
+}
+void ref_bspline_free(void *h) { delete (handle_base *)h; }
+void ref_bspline_prefilter(void *h, int d) { ((handle_base *)h)->prefilter(d); }
+void ref_bspline_spherical(void *h, int d) { ((handle_base *)h)->spherical(d); }
+void ref_bspline_brace(void *h, int axis) { ((handle_base *)h)->brace(axis); }
+void ref_bspline_geometry(void *h, long *o) { ((handle_base *)h)->geometry(o); }
+void ref_bspline_container(void *h, float *out) {
+  auto *b = (handle_base *)h;
+  long g[10];
+  b->geometry(g);
+  std::memcpy(out, b->container_data(), sizeof(float) * g[0] * g[1] * b->nch);
+}
+void ref_bspline_eval(void *h, const float *crd, long n, float *out) {
+  ((handle_base *)h)->eval(crd, n, out);
+}
+void ref_bspline_process_affine(void *h, long w, long hh, const float *aff,
+                                float *out) {
+  ((handle_base *)h)->process_affine(w, hh, aff, out);
+}
+
+// b-spline basis weights for one delta (basis.h:650-690), math type float
+void ref_basis_weights(int degree, float delta, float *w) {
+  zimt::basis_functor<float> bf(degree);
+  bf(w, delta);
+}
+
+// prefilter poles and the weight matrix are long double in the reference
+void ref_poles(int degree, long double *out) {
+  for (int i = 0; i < degree / 2; i++)
+    out[i] = zimt_constants::precomputed_poles[degree][i];
+}
+
+// zimt::prefilter over a plain (frameless) w x h image, both axes, in place:
+// what cubemap_t::prefilter does per IR section with NATURAL x NATURAL
+// (cubemap.h:921-946), default tolerance
+void ref_filter_2d(float *data, long w, long h, int nch, int degree, int bc0,
+                   int bc1) {
+#define REF_F2D(N)                                                          \
+  {                                                                         \
+    typedef zimt::xel_t<float, N> px_t;                                     \
+    zimt::view_t<2, px_t> v((px_t *)data, {1L, w},                          \
+                            {std::size_t(w), std::size_t(h)});              \
+    zimt::prefilter(v, v, {zimt::bc_code(bc0), zimt::bc_code(bc1)}, degree); \
+  }
+  switch (nch) {
+    case 1: REF_F2D(1) break;
+    case 2: REF_F2D(2) break;
+    case 3: REF_F2D(3) break;
+    case 4: REF_F2D(4) break;
+  }
+#undef REF_F2D
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+"""CPU oracle vs fixtures generated from the reference's own zimt headers
+(tests/golden/make_golden.py). Bit-exact: float32 results compared as uint32."""
+import os
+
+import numpy as np
+import pytest
+
+import euo
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "zimt_golden.npz"))
+EPS = float(np.finfo(np.float32).eps)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_same(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    assert a.shape == b.shape
+    bad = np.argwhere(bits(a) != bits(b))
+    assert bad.size == 0, f"{len(bad)} floats differ, first at {bad[0]}: {a[tuple(bad[0])]!r} vs {b[tuple(bad[0])]!r}"
+
+
+@pytest.mark.parametrize("degree", range(10))
+def test_basis_weights(degree):
+    for i, d in enumerate(G["weights_deltas"]):
+        assert_same(euo.basis_weights(degree, float(d)), G[f"weights_d{degree}"][i])
+
+
+@pytest.mark.parametrize("degree", range(2, 10))
+def test_poles(degree):
+    got = euo.poles(degree).astype(np.float64)
+    ref = G[f"poles_d{degree}"]
+    assert got.shape == ref.shape
+    assert np.all(got.astype(np.float32) == ref.astype(np.float32))
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-15
+
+
+@pytest.mark.parametrize("k", range(len(G["spl_cases"])))
+def test_prefilter_brace_eval(k):
+    w, h, n, deg, pdeg, b0, b1 = (int(v) for v in G["spl_cases"][k])
+    s = euo.BSpline(G[f"spl{k}_core"], deg, b0, b1)
+    g = G[f"spl{k}_geometry"]
+    assert list(s.s.shape) == [g[0], g[1]]
+    assert list(s.s.left) == [g[4], g[5]] and list(s.s.right) == [g[6], g[7]]
+    s.prefilter(pdeg)
+    assert_same(s.container, G[f"spl{k}_container"])
+    assert_same(s.eval(G[f"spl{k}_crd"]), G[f"spl{k}_val"])
+
+
+@pytest.mark.parametrize("k", range(len(G["sph_cases"])))
+def test_spherical_prefilter(k):
+    w, h, n, deg, pdeg = (int(v) for v in G["sph_cases"][k])
+    s = euo.BSpline(G[f"sph{k}_core"], deg, euo.PERIODIC, euo.REFLECT)
+    s.spherical_prefilter(pdeg)
+    assert_same(s.container, G[f"sph{k}_container"])
+    assert_same(s.eval(G[f"sph{k}_crd"]), G[f"sph{k}_val"])
+
+
+@pytest.mark.parametrize("k", range(len(G["nat_cases"])))
+def test_natural_section_filter(k):
+    w, n, deg = (int(v) for v in G["nat_cases"][k])
+    b = G[f"nat{k}_in"].copy()
+    for c in range(n):
+        euo.lib().euo_filter_lines(b.ctypes.data + 4 * c, w, w * n, w, n,
+                                   euo.NATURAL, deg, EPS)
+    for c in range(n):
+        euo.lib().euo_filter_lines(b.ctypes.data + 4 * c, w, n, w, w * n,
+                                   euo.NATURAL, deg, EPS)
+    assert_same(b, G[f"nat{k}_out"])
+
+
+@pytest.mark.parametrize("name,w,h", [("drv_out", 600, 3), ("drv_short", 11, 2)])
+def test_driver_raster(name, w, h):
+    """zimt::process (segments of 512, vectors of 16, leftover lanes) equals
+    per-pixel evaluation: the driver adds no arithmetic of its own."""
+    s = euo.BSpline(G["drv_core"], 3, euo.PERIODIC, euo.REFLECT)
+    s.prefilter(3)
+    a = G["drv_aff"]
+    x = np.arange(w, dtype=np.float32) * a[1] + a[0]
+    y = np.arange(h, dtype=np.float32) * a[3] + a[2]
+    crd = np.stack(np.broadcast_arrays(x[None, :], y[:, None]), -1).reshape(-1, 2)
+    assert_same(s.eval(crd).reshape(h, w, 3), G[name])
