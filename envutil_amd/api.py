@@ -1,0 +1,333 @@
+"""ctypes binding of include/eu_hip.h and a host mirror of envutil's job surface."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SPHERICAL, CYLINDRICAL, RECTILINEAR, STEREOGRAPHIC, FISHEYE, CUBEMAP, BIATAN6 = range(7)
+BC_MIRROR, BC_PERIODIC, BC_REFLECT, BC_NATURAL, BC_CONSTANT, BC_ZEROPAD, BC_GUESS = range(7)
+PROJECTION_NAMES = ["spherical", "cylindrical", "rectilinear", "stereographic",
+                    "fisheye", "cubemap", "biatan6"]
+
+
+class EuError(RuntimeError):
+    pass
+
+
+class Facet(C.Structure):
+    """struct eu_facet"""
+    _fields_ = [("projection", C.c_int32), ("nchannels", C.c_int32),
+                ("hfov", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("window_width", C.c_int32), ("window_height", C.c_int32),
+                ("window_x_offset", C.c_int32), ("window_y_offset", C.c_int32),
+                ("yaw", C.c_double), ("pitch", C.c_double), ("roll", C.c_double),
+                ("brighten", C.c_double), ("step", C.c_double),
+                ("has_lcp", C.c_int32),
+                ("a", C.c_double), ("b", C.c_double), ("c", C.c_double),
+                ("h", C.c_double), ("v", C.c_double), ("s", C.c_double),
+                ("shear_g", C.c_double), ("shear_t", C.c_double)]
+
+
+class Container(C.Structure):
+    """struct eu_container"""
+    _fields_ = [("shape", C.c_int64 * 2), ("left", C.c_int64 * 2),
+                ("right", C.c_int64 * 2), ("core", C.c_int64 * 2)]
+
+
+class Target(C.Structure):
+    """struct eu_target"""
+    _fields_ = [("projection", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("x0", C.c_double), ("x1", C.c_double), ("y0", C.c_double), ("y1", C.c_double),
+                ("yaw", C.c_double), ("pitch", C.c_double), ("roll", C.c_double),
+                ("nchannels", C.c_int32), ("ntaps", C.c_int32),
+                ("taps", C.POINTER(C.c_float)),
+                ("row_begin", C.c_int32), ("row_end", C.c_int32), ("stage", C.c_int32)]
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libeu_hip.so")
+
+
+def build(force=False):
+    """compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)"""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", HERE, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", HERE])
+    return lib_path()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise EuError(f"{p} is missing: run envutil_amd.build() (hipcc, gfx950). "
+                      "There is no fallback implementation.")
+    L = C.CDLL(p)
+    vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+    L.eu_hip_last_error.restype = C.c_char_p
+    L.eu_hip_get_step.restype = f64
+    L.eu_hip_get_step.argtypes = [i32, i32, i32, f64]
+    L.eu_hip_get_extent.argtypes = [i32, i32, i32, f64, vp]
+    L.eu_hip_make_spread.argtypes = [i32, i32, C.c_float, C.c_float, C.c_float, vp, i32]
+    L.eu_hip_cubemap_metrics.argtypes = [i32, f64, i32, i32, vp, vp, vp, vp]
+    L.eu_hip_container_geometry.argtypes = [i32, i32, i32, C.c_int64, C.c_int64, vp]
+    L.eu_hip_source_load.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.eu_hip_source_adopt.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.eu_hip_source_download.argtypes = [vp, vp, C.c_size_t]
+    L.eu_hip_source_info.argtypes = [vp, vp, vp]
+    L.eu_hip_source_release.argtypes = [vp]
+    L.eu_hip_render.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
+    L.eu_hip_render_timed.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
+    L.eu_hip_malloc.argtypes = [vp, C.c_size_t]
+    L.eu_hip_free.argtypes = [vp]
+    L.eu_hip_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    L.eu_hip_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise EuError(f"eu_hip error {rc}: {lib().eu_hip_last_error().decode()}")
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().eu_hip_device_count()
+
+
+def get_extent(projection, width, height, hfov):
+    e = np.zeros(4, np.float64)
+    _check(lib().eu_hip_get_extent(projection, width, height, hfov, _ptr(e)))
+    return e
+
+
+def get_step(projection, width, height, hfov):
+    return lib().eu_hip_get_step(projection, width, height, hfov)
+
+
+def make_spread(w, h=0, d=1.0, sigma=0.0, threshold=0.0):
+    n = max(w, 2) * max(h if h > 0 else max(w, 2), 1)
+    out = np.zeros((n, 3), np.float32)
+    k = _check(lib().eu_hip_make_spread(w, h, d, sigma, threshold, _ptr(out), n))
+    return out[:k].copy()
+
+
+def cubemap_metrics(face_px, face_fov=math.pi / 2, support_min=8, tile_px=64):
+    sec, lf = C.c_int64(), C.c_int64()
+    refc, m2p = C.c_double(), C.c_double()
+    _check(lib().eu_hip_cubemap_metrics(face_px, face_fov, support_min, tile_px,
+                                        C.byref(sec), C.byref(lf), C.byref(refc), C.byref(m2p)))
+    return dict(section_px=sec.value, left_frame_px=lf.value, refc_md=refc.value,
+                model_to_px=m2p.value)
+
+
+def container_geometry(degree, bc0, bc1, w, h):
+    g = Container()
+    _check(lib().eu_hip_container_geometry(degree, bc0, bc1, w, h, C.byref(g)))
+    return g
+
+
+class facet_spec:
+    """Host mirror of envutil's facet_spec (envutil_basic.h:432-520): the fields
+    the render path reads. Angles in DEGREES here, as on envutil's command
+    line; converted to radians when the C struct is built
+    (envutil_main.cc:957-960)."""
+
+    def __init__(self, projection, width, height, hfov, nchannels=3, yaw=0.0,
+                 pitch=0.0, roll=0.0, brighten=1.0, window=None):
+        self.projection = projection
+        self.width, self.height = width, height
+        self.hfov = hfov
+        self.nchannels = nchannels
+        self.yaw, self.pitch, self.roll = yaw, pitch, roll
+        self.brighten = brighten
+        self.window = window or (width, height, 0, 0)
+
+    def c_struct(self):
+        f = Facet()
+        f.projection = self.projection
+        f.nchannels = self.nchannels
+        f.hfov = math.radians(self.hfov)
+        f.width, f.height = self.width, self.height
+        (f.window_width, f.window_height, f.window_x_offset, f.window_y_offset) = self.window
+        f.yaw, f.pitch, f.roll = (math.radians(v) for v in (self.yaw, self.pitch, self.roll))
+        f.brighten = self.brighten
+        f.step = get_step(self.projection, self.width, self.height, f.hfov)
+        return f
+
+
+class Source:
+    """A source image resident in HBM (the asset_handler entry,
+    environment.h:84-227)."""
+
+    def __init__(self, handle, fct):
+        self.handle = handle
+        self.fct = fct
+
+    @classmethod
+    def load(cls, fct, pixels, spline_degree, prefilter_degree=None, support_min=8,
+             tile_size=64):
+        """pixels -> braced + prefiltered coefficients, on the device"""
+        if prefilter_degree is None:
+            prefilter_degree = spline_degree
+        pixels = np.ascontiguousarray(pixels, np.float32)
+        cf = fct.c_struct()
+        h = C.c_void_p()
+        _check(lib().eu_hip_source_load(C.byref(cf), _ptr(pixels), spline_degree,
+                                        prefilter_degree, support_min, tile_size, C.byref(h)))
+        return cls(h, fct)
+
+    @classmethod
+    def adopt(cls, fct, container, spline_degree, bc0=BC_REFLECT, bc1=BC_REFLECT,
+              support_min=8, tile_size=64):
+        """upload an already braced + prefiltered container"""
+        container = np.ascontiguousarray(container, np.float32)
+        cf = fct.c_struct()
+        h = C.c_void_p()
+        _check(lib().eu_hip_source_adopt(C.byref(cf), _ptr(container), spline_degree, bc0,
+                                         bc1, support_min, tile_size, C.byref(h)))
+        return cls(h, fct)
+
+    def info(self):
+        g = Container()
+        n = C.c_int()
+        _check(lib().eu_hip_source_info(self.handle, C.byref(g), C.byref(n)))
+        return g, n.value
+
+    def download(self):
+        g, n = self.info()
+        out = np.zeros((g.shape[1], g.shape[0], n), np.float32)
+        _check(lib().eu_hip_source_download(self.handle, _ptr(out), out.size))
+        return out
+
+    def release(self):
+        if self.handle:
+            lib().eu_hip_source_release(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class arguments:
+    """Host mirror of the target half of envutil's global `args`
+    (envutil_basic.h:633-705): projection, size, hfov -> extent, camera
+    orientation (degrees), spline degree, twining."""
+
+    def __init__(self, projection, width, height, hfov, yaw=0.0, pitch=0.0, roll=0.0,
+                 spline_degree=1, prefilter_degree=None, twine=0, twine_width=1.0,
+                 twine_sigma=0.0, twine_threshold=0.0, support_min=8, tile_size=64):
+        self.projection = projection
+        self.width, self.height = width, height
+        self.hfov = hfov
+        self.yaw, self.pitch, self.roll = yaw, pitch, roll
+        self.spline_degree = spline_degree
+        self.prefilter_degree = spline_degree if prefilter_degree is None else prefilter_degree
+        self.twine = twine
+        self.twine_width, self.twine_sigma = twine_width, twine_sigma
+        self.twine_threshold = twine_threshold
+        self.support_min, self.tile_size = support_min, tile_size
+        # envutil_main.cc:1203-1232
+        self.extent = get_extent(projection, width, height, math.radians(hfov))
+        self.step = (self.extent[1] - self.extent[0]) / width
+        self.twine_spread = None
+        if twine:
+            # arguments::twine_setup, envutil_main.cc:1405-1616 (explicit twine)
+            self.twine_spread = make_spread(twine, twine, twine_width, twine_sigma,
+                                            twine_threshold)
+
+    def target(self, nchannels, row_begin=0, row_end=None, stage=0):
+        t = Target()
+        t.projection = self.projection
+        t.width, t.height = self.width, self.height
+        t.x0, t.x1, t.y0, t.y1 = (float(v) for v in self.extent)
+        t.yaw, t.pitch, t.roll = (math.radians(v) for v in (self.yaw, self.pitch, self.roll))
+        t.nchannels = nchannels
+        if self.twine_spread is not None:
+            t.ntaps = len(self.twine_spread)
+            t.taps = self.twine_spread.ctypes.data_as(C.POINTER(C.c_float))
+        t.row_begin = row_begin
+        t.row_end = self.height if row_end is None else row_end
+        t.stage = stage
+        return t
+
+
+def render(args, sources, nchannels=None, row_begin=0, row_end=None, stage=0, out=None):
+    """zimt::process(shape, get, act, put, bill) for rows [row_begin, row_end):
+    returns (rows, width, nch) float32 on the host."""
+    if not isinstance(sources, (list, tuple)):
+        sources = [sources]
+    nch = nchannels or sources[0].fct.nchannels
+    t = args.target(nch, row_begin, row_end, stage)
+    och = 3 if stage else nch
+    rows = t.row_end - t.row_begin
+    if out is None:
+        out = np.zeros((rows, args.width, och), np.float32)
+    arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
+    _check(lib().eu_hip_render(C.byref(t), arr, len(sources), _ptr(out),
+                               args.width * och * 4, 0, None))
+    return out
+
+
+def render_timed(args, sources, out_dev_ptr, iters, nchannels=None, row_begin=0,
+                 row_end=None):
+    """kernel-only timing with HIP events on the library's stream; the output
+    stays in HBM at out_dev_ptr. Returns mean milliseconds per launch."""
+    if not isinstance(sources, (list, tuple)):
+        sources = [sources]
+    nch = nchannels or sources[0].fct.nchannels
+    t = args.target(nch, row_begin, row_end, 0)
+    arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
+    ms = C.c_float()
+    _check(lib().eu_hip_render_timed(C.byref(t), arr, len(sources), C.c_void_p(out_dev_ptr),
+                                     args.width * nch * 4, iters, C.byref(ms)))
+    return ms.value
+
+
+class _hip_dispatch:
+    """dispatch_base (envutil_dispatch.h:49-65) for the HIP back-end:
+    payload(nchannels, ninputs, projection) runs one render job described by
+    the `args` / sources it was bound to and returns 0, like the reference."""
+
+    hwy_target_name = "gfx950"
+    hwy_target_str = "HIP/CDNA4"
+
+    def __init__(self):
+        self.args = None
+        self.sources = None
+        self.result = None
+
+    def bind(self, args, sources):
+        self.args, self.sources = args, sources
+        return self
+
+    def payload(self, nchannels, ninputs, projection):
+        a = self.args
+        if projection != a.projection:
+            raise EuError("payload projection differs from args.projection")
+        if (ninputs == 9) != (a.twine_spread is not None):
+            raise EuError("ninputs must be 9 with twining and 3 without")
+        self.result = render(a, self.sources, nchannels)
+        return 0
+
+
+def get_dispatch():
+    return _hip_dispatch()

@@ -1,0 +1,477 @@
+// C ABI (include/eu_hip.h): host glue between the reference-shaped job
+// description and the HIP kernels. No CPU rendering path exists in this
+// library: without a HIP device every render/load call fails with
+// EU_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+#include "eu_device.h"
+#include "eu_setup_math.h"
+
+extern "C" int eu_launch_render(const eu_render_params *p, void *stream);
+extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int nch,
+                                   int bc0, int bc1, int prefilter_degree, int spherical,
+                                   void *stream);
+extern "C" int eu_launch_cubemap_build(const float *faces_dev, float *ir_dev, int nch,
+                                       long face_px, long section_px, long left_frame,
+                                       long right_frame, double refc_md, double model_to_px,
+                                       int prefilter_degree, void *stream);
+
+struct eu_source {
+  eu_facet fct;
+  eu_container geom;
+  int bc[2];
+  int degree;
+  int nch;
+  float *dev;            // braced container in HBM
+  size_t nfloats;
+  eu_src_dev sd;
+};
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+struct context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  float *col = nullptr, *row = nullptr, *taps = nullptr;
+  size_t col_cap = 0, row_cap = 0, taps_cap = 0;
+  float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
+} g;
+
+#define HIPCHK(call)                                                          \
+  do {                                                                        \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess)                                                     \
+      return fail(EU_ERR_NO_DEVICE, std::string(#call ": ") + hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure_init()
+{
+  if (g.device >= 0) return EU_OK;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(EU_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  int dev = 0;
+  const char *lr = getenv("LOCAL_RANK");
+  if (lr) dev = atoi(lr) % n;
+  HIPCHK(hipSetDevice(dev));
+  HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  g.device = dev;
+  return EU_OK;
+}
+
+int grow(float **p, size_t *cap, size_t need)
+{
+  if (*cap >= need) return EU_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  HIPCHK(hipMalloc((void **)p, need * sizeof(float)));
+  *cap = need;
+  return EU_OK;
+}
+
+bool is_cube(int prj) { return prj == EU_CUBEMAP || prj == EU_BIATAN6; }
+
+// evaluator + mount parameters (eval.h:2039-2164, environment.h:594-633)
+void fill_src_dev(eu_source *s)
+{
+  eu_src_dev &d = s->sd;
+  const eu_facet &f = s->fct;
+  memset(&d, 0, sizeof d);
+  const eu_container &g0 = s->geom;
+  d.base = s->dev + ((size_t)g0.left[1] * g0.shape[0] + g0.left[0]) * s->nch;
+  d.es0 = s->nch;
+  d.es1 = (long long)s->nch * g0.shape[0];
+  d.prj = f.projection; d.nch = s->nch; d.degree = s->degree;
+  float lo[2], up[2]; int gt[2];
+  for (int a = 0; a < 2; a++) {
+    int bc = s->bc[a];
+    long double l = 0.0L, u = (long double)(g0.core[a] - 1);
+    if (bc == EU_BC_REFLECT || bc == EU_BC_PERIODIC) { l = -0.5L; u += 0.5L; }
+    lo[a] = (float)l; up[a] = (float)u;
+    if (g0.core[a] == 1) { bc = EU_BC_CONSTANT; lo[a] = up[a] = 0.0f; }
+    gt[a] = bc == EU_BC_PERIODIC ? 2 : (bc == EU_BC_MIRROR || bc == EU_BC_REFLECT) ? 1 : 0;
+  }
+  d.gate0 = gt[0]; d.gate1 = gt[1];
+  d.lower0 = lo[0]; d.upper0 = up[0]; d.lower1 = lo[1]; d.upper1 = up[1];
+  d.brighten = (float)f.brighten;
+  eu::weight_matrix(s->degree, d.wm);
+  if (is_cube(f.projection)) return;
+  double te[4], we[4];
+  eu::get_extent(f.projection, f.width, f.height, f.hfov, te);
+  double wx = te[1] - te[0], wy = te[3] - te[2];
+  // environment.h:617-633, including its use of total_width / window_width
+  // in the y terms
+  double px = double(f.window_x_offset) / f.width;
+  double py = double(f.window_y_offset) / f.width;
+  we[0] = te[0] + px * wx; we[2] = te[2] + py * wy;
+  px = double(f.window_x_offset + f.window_width) / f.width;
+  py = double(f.window_y_offset + f.window_width) / f.width;
+  we[1] = te[0] + px * wx; we[3] = te[2] + py * wy;
+  d.tex_x0 = te[0]; d.tex_y0 = te[2];
+  d.ext_w = (float)(te[1] - te[0]); d.ext_h = (float)(te[3] - te[2]);
+  d.total_w = (float)f.width; d.total_h = (float)f.height;
+  d.win_x_off = (float)f.window_x_offset; d.win_y_off = (float)f.window_y_offset;
+  d.wex0 = (float)we[0]; d.wex1 = (float)we[1]; d.wex2 = (float)we[2]; d.wex3 = (float)we[3];
+}
+
+int check_facet(const eu_facet *f)
+{
+  if (!f) return fail(EU_ERR_ARGUMENT, "null facet");
+  if (f->nchannels < 1 || f->nchannels > 4) return fail(EU_ERR_ARGUMENT, "nchannels must be 1..4");
+  if (f->projection < 0 || f->projection > EU_BIATAN6) return fail(EU_ERR_ARGUMENT, "unknown source projection");
+  if (f->width <= 0 || f->height <= 0) return fail(EU_ERR_ARGUMENT, "empty source image");
+  if (f->projection == EU_FISHEYE)
+    return fail(EU_ERR_UNSUPPORTED, "fisheye sources need libm-exact sinf/cosf on the device: not built yet");
+  if (f->has_lcp)
+    return fail(EU_ERR_UNSUPPORTED, "PTO lens correction (pto_planar) not built yet");
+  return EU_OK;
+}
+
+// allocates the eu_source and its container for the facet
+int new_source(const eu_facet *fct, int spline_degree, int bc0, int bc1, int support_min,
+               int tile_size, eu_source **out)
+{
+  if (spline_degree < 0 || spline_degree > EU_MAX_DEGREE)
+    return fail(EU_ERR_ARGUMENT, "spline degree out of range");
+  eu_source *s = new (std::nothrow) eu_source;
+  if (!s) return fail(EU_ERR_MEMORY, "host allocation failed");
+  memset(s, 0, sizeof *s);
+  s->fct = *fct;
+  s->degree = spline_degree;
+  s->nch = fct->nchannels;
+  if (is_cube(fct->projection)) {
+    // IR image: container == core, REFLECT x REFLECT (cubemap.h:576-583)
+    eu::metrics m = eu::make_metrics(fct->width, fct->hfov, support_min, tile_size);
+    s->geom.shape[0] = s->geom.core[0] = m.section_px;
+    s->geom.shape[1] = s->geom.core[1] = 6 * m.section_px;
+    s->geom.left[0] = s->geom.left[1] = s->geom.right[0] = s->geom.right[1] = 0;
+    s->bc[0] = s->bc[1] = EU_BC_REFLECT;
+  } else {
+    eu::container_geometry(spline_degree, bc0, bc1, fct->window_width, fct->window_height, &s->geom);
+    s->bc[0] = bc0; s->bc[1] = bc1;
+  }
+  s->nfloats = (size_t)s->geom.shape[0] * s->geom.shape[1] * s->nch;
+  hipError_t e = hipMalloc((void **)&s->dev, s->nfloats * sizeof(float));
+  if (e != hipSuccess) { delete s; return fail(EU_ERR_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  fill_src_dev(s);
+  if (is_cube(fct->projection)) {
+    eu::metrics m = eu::make_metrics(fct->width, fct->hfov, support_min, tile_size);
+    s->sd.refc_md = (float)m.refc_md;
+    s->sd.model_to_px = (float)m.model_to_px;
+    s->sd.section_px = (int)m.section_px;
+  }
+  *out = s;
+  return EU_OK;
+}
+
+// boundary conditions source_t picks (environment.h:638-644)
+void source_bcs(const eu_facet *f, int *bc0, int *bc1)
+{
+  *bc0 = EU_BC_REFLECT; *bc1 = EU_BC_REFLECT;
+  if ((f->projection == EU_SPHERICAL || f->projection == EU_CYLINDRICAL)
+      && std::fabs(f->hfov - 2.0 * M_PI) < .000001)
+    *bc0 = EU_BC_PERIODIC;
+}
+
+int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *out_dev,
+                 size_t row_stride_bytes, eu_render_params *p)
+{
+  if (!t || !srcs || !out_dev) return fail(EU_ERR_ARGUMENT, "null argument");
+  if (nsrc != 1)
+    return fail(EU_ERR_UNSUPPORTED, "multi-facet synopsis (voronoi_syn) not built yet: nsrc must be 1");
+  const eu_source *s = srcs[0];
+  if (!s) return fail(EU_ERR_HANDLE, "null source");
+  if (t->nchannels != s->nch)
+    return fail(EU_ERR_UNSUPPORTED, "channel adaption (repix_t) not built yet: target and source channel counts differ");
+  if (t->width <= 0 || t->height <= 0) return fail(EU_ERR_ARGUMENT, "empty target");
+  if (t->row_begin < 0 || t->row_end > t->height || t->row_begin > t->row_end)
+    return fail(EU_ERR_ARGUMENT, "row range outside the target");
+  if (t->ntaps < 0 || t->ntaps > EU_MAX_TAPS || (t->ntaps > 0 && !t->taps))
+    return fail(EU_ERR_ARGUMENT, "bad twining tap table");
+  if ((t->projection == EU_CUBEMAP || t->projection == EU_BIATAN6) && t->height != 6 * t->width)
+    return fail(EU_ERR_ARGUMENT, "cubemap targets are 1:6");
+  if (row_stride_bytes % sizeof(float))
+    return fail(EU_ERR_ARGUMENT, "row stride must be a multiple of 4 bytes");
+  const bool twine = t->ntaps > 0;
+  // orientation: envutil_payload.cc:1923-1948
+  eu::mat3 r_cam = eu::make_r3(t->roll, t->pitch, t->yaw, false);
+  eu::mat3 r_fct = eu::make_r3(s->fct.roll, s->fct.pitch, s->fct.yaw, true);
+  eu::mat3 basis = eu::rotate(r_cam, r_fct);
+  eu::stepper_tables tb;
+  if (!eu::build_stepper_tables(*t, basis, twine, twine, tb))
+    return fail(EU_ERR_UNSUPPORTED, "fisheye/stereographic target steppers not built yet");
+  int rc;
+  if ((rc = grow(&g.col, &g.col_cap, tb.col.size()))) return rc;
+  if ((rc = grow(&g.row, &g.row_cap, tb.row.size()))) return rc;
+  HIPCHK(hipMemcpyAsync(g.col, tb.col.data(), tb.col.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemcpyAsync(g.row, tb.row.data(), tb.row.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+  std::vector<float> taps;
+  if (twine) {
+    // twine_t ctor: x, y pre-multiplied by the bias 4.0 (twining.h:106-121)
+    taps.assign(t->taps, t->taps + 3 * (size_t)t->ntaps);
+    for (int k = 0; k < t->ntaps; k++) { taps[3 * k] *= 4.0f; taps[3 * k + 1] *= 4.0f; }
+    if ((rc = grow(&g.taps, &g.taps_cap, taps.size()))) return rc;
+    HIPCHK(hipMemcpyAsync(g.taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+  }
+  // the host vectors die at return: the copies must have left them
+  HIPCHK(hipStreamSynchronize(g.stream));
+  memset(p, 0, sizeof *p);
+  p->width = t->width; p->height = t->height;
+  p->row_begin = t->row_begin; p->row_end = t->row_end;
+  p->form = tb.form; p->norm_mode = tb.norm_mode;
+  p->twine = twine; p->ntaps = t->ntaps; p->stage = t->stage; p->nch = s->nch;
+  p->col = g.col; p->row = g.row; p->taps = g.taps;
+  p->out = out_dev;
+  p->out_stride = (long long)(row_stride_bytes / sizeof(float));
+  p->src = s->sd;
+  return EU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *eu_hip_last_error(void) { return g_err.c_str(); }
+
+int eu_hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int eu_hip_init(int device)
+{
+  int n = eu_hip_device_count();
+  if (n <= 0) return fail(EU_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (device < 0 || device >= n) return fail(EU_ERR_ARGUMENT, "device index out of range");
+  if (g.device == device) return EU_OK;
+  HIPCHK(hipSetDevice(device));
+  if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  g.device = device;
+  return EU_OK;
+}
+
+int eu_hip_get_extent(int prj, int w, int h, double hfov, double *e)
+{
+  if (!e || prj < 0 || prj > EU_BIATAN6) return fail(EU_ERR_ARGUMENT, "bad projection");
+  eu::get_extent(prj, w, h, hfov, e);
+  return EU_OK;
+}
+
+double eu_hip_get_step(int prj, int w, int h, double hfov) { return eu::get_step(prj, w, h, hfov); }
+
+int eu_hip_make_spread(int w, int h, float d, float sigma, float threshold, float *taps, int max_taps)
+{
+  std::vector<float> v;
+  int n = eu::make_spread(w, h, d, sigma, threshold, v);
+  if (n > max_taps) return fail(EU_ERR_ARGUMENT, "tap buffer too small");
+  memcpy(taps, v.data(), v.size() * sizeof(float));
+  return n;
+}
+
+int eu_hip_cubemap_metrics(int face_px, double face_fov, int support_min, int tile_px,
+                           int64_t *section_px, int64_t *left_frame_px, double *refc_md,
+                           double *model_to_px)
+{
+  if (face_px <= 0 || tile_px <= 0 || (tile_px & (tile_px - 1)) || face_fov < M_PI_2 - 1e-12)
+    return fail(EU_ERR_ARGUMENT, "bad cubemap metrics arguments");
+  eu::metrics m = eu::make_metrics(face_px, face_fov, support_min, tile_px);
+  if (section_px) *section_px = m.section_px;
+  if (left_frame_px) *left_frame_px = m.left_frame_px;
+  if (refc_md) *refc_md = m.refc_md;
+  if (model_to_px) *model_to_px = m.model_to_px;
+  return EU_OK;
+}
+
+int eu_hip_container_geometry(int degree, int bc0, int bc1, int64_t w, int64_t h, eu_container *out)
+{
+  if (!out || degree < 0 || degree > EU_MAX_DEGREE || w <= 0 || h <= 0)
+    return fail(EU_ERR_ARGUMENT, "bad container geometry arguments");
+  eu::container_geometry(degree, bc0, bc1, w, h, out);
+  return EU_OK;
+}
+
+int eu_hip_source_adopt(const eu_facet *fct, const float *container, int spline_degree,
+                        int bc0, int bc1, int support_min, int tile_size, eu_source **out)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if ((rc = check_facet(fct))) return rc;
+  if (!container || !out) return fail(EU_ERR_ARGUMENT, "null argument");
+  eu_source *s = nullptr;
+  if ((rc = new_source(fct, spline_degree, bc0, bc1, support_min, tile_size, &s))) return rc;
+  hipError_t e = hipMemcpy(s->dev, container, s->nfloats * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(s->dev); delete s; return fail(EU_ERR_NO_DEVICE, hipGetErrorString(e)); }
+  *out = s;
+  return EU_OK;
+}
+
+int eu_hip_source_load(const eu_facet *fct, const float *pixels, int spline_degree,
+                       int prefilter_degree, int support_min, int tile_size, eu_source **out)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if ((rc = check_facet(fct))) return rc;
+  if (!pixels || !out) return fail(EU_ERR_ARGUMENT, "null argument");
+  if (prefilter_degree < 0 || prefilter_degree > EU_MAX_DEGREE)
+    return fail(EU_ERR_ARGUMENT, "prefilter degree out of range");
+  int bc0, bc1;
+  source_bcs(fct, &bc0, &bc1);
+  eu_source *s = nullptr;
+  if ((rc = new_source(fct, spline_degree, bc0, bc1, support_min, tile_size, &s))) return rc;
+  const int nch = s->nch;
+  hipError_t e = hipSuccess;
+  if (is_cube(fct->projection)) {
+    eu::metrics m = eu::make_metrics(fct->width, fct->hfov, support_min, tile_size);
+    size_t nface = (size_t)6 * m.face_px * m.face_px * nch;
+    float *faces = nullptr;
+    e = hipMalloc((void **)&faces, nface * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(faces, pixels, nface * sizeof(float), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) {
+      rc = eu_launch_cubemap_build(faces, s->dev, nch, m.face_px, m.section_px, m.left_frame_px,
+                                   m.right_frame_px, m.refc_md, m.model_to_px, prefilter_degree,
+                                   g.stream);
+      e = hipStreamSynchronize(g.stream);
+    }
+    if (faces) (void)hipFree(faces);
+  } else {
+    // pixels -> core of the container (2-D strided copy), then prefilter + brace
+    const eu_container &gm = s->geom;
+    e = hipMemsetAsync(s->dev, 0, s->nfloats * sizeof(float), g.stream);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(s->dev + ((size_t)gm.left[1] * gm.shape[0] + gm.left[0]) * nch,
+                           (size_t)gm.shape[0] * nch * sizeof(float), pixels,
+                           (size_t)gm.core[0] * nch * sizeof(float),
+                           (size_t)gm.core[0] * nch * sizeof(float), (size_t)gm.core[1],
+                           hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) {
+      // source_t ctor, environment.h:905-936: full spherical images get the
+      // two-axis periodic scheme, everything else bspline::prefilter()
+      int spherical = fct->projection == EU_SPHERICAL && std::fabs(fct->hfov - 2.0 * M_PI) < .000001
+                      && fct->width == 2 * fct->height;
+      rc = eu_launch_prefilter(s->dev, &s->geom, nch, bc0, bc1, prefilter_degree, spherical, g.stream);
+      e = hipStreamSynchronize(g.stream);
+    }
+  }
+  if (e != hipSuccess || rc) {
+    (void)hipFree(s->dev);
+    delete s;
+    if (e != hipSuccess) return fail(EU_ERR_NO_DEVICE, hipGetErrorString(e));
+    return fail(rc, "device set-up stage failed");
+  }
+  *out = s;
+  return EU_OK;
+}
+
+int eu_hip_source_download(const eu_source *src, float *container, size_t nfloats)
+{
+  if (!src || !container) return fail(EU_ERR_HANDLE, "null argument");
+  if (nfloats != src->nfloats) return fail(EU_ERR_ARGUMENT, "container size mismatch");
+  HIPCHK(hipMemcpy(container, src->dev, nfloats * sizeof(float), hipMemcpyDeviceToHost));
+  return EU_OK;
+}
+
+int eu_hip_source_info(const eu_source *src, eu_container *geom, int *nch)
+{
+  if (!src) return fail(EU_ERR_HANDLE, "null source");
+  if (geom) *geom = src->geom;
+  if (nch) *nch = src->nch;
+  return EU_OK;
+}
+
+int eu_hip_source_release(eu_source *src)
+{
+  if (!src) return EU_OK;
+  if (src->dev) (void)hipFree(src->dev);
+  delete src;
+  return EU_OK;
+}
+
+int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float *out,
+                  size_t out_row_stride_bytes, int out_on_device, void *stream)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if (!trg) return fail(EU_ERR_ARGUMENT, "null target");
+  const int och = trg->stage ? 3 : trg->nchannels;
+  const size_t min_stride = (size_t)trg->width * och * sizeof(float);
+  if (out_row_stride_bytes < min_stride) return fail(EU_ERR_ARGUMENT, "row stride smaller than a row");
+  eu_render_params p;
+  hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+  if (out_on_device) {
+    if ((rc = build_params(trg, srcs, nsrc, out, out_row_stride_bytes, &p))) return rc;
+    if (eu_launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+    return EU_OK;
+  }
+  const size_t rows = (size_t)(trg->row_end - trg->row_begin);
+  if (!rows) return EU_OK;
+  if ((rc = grow(&g.stage, &g.stage_cap, rows * trg->width * och))) return rc;
+  if ((rc = build_params(trg, srcs, nsrc, g.stage, min_stride, &p))) return rc;
+  if (eu_launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+  HIPCHK(hipMemcpy2DAsync(out, out_row_stride_bytes, g.stage, min_stride, min_stride, rows,
+                          hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return EU_OK;
+}
+
+int eu_hip_sync(void)
+{
+  if (g.device < 0) return EU_OK;
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return EU_OK;
+}
+
+int eu_hip_render_timed(const eu_target *trg, eu_source *const *srcs, int nsrc, float *out_dev,
+                        size_t out_row_stride_bytes, int iters, float *mean_ms)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if (iters <= 0 || !mean_ms) return fail(EU_ERR_ARGUMENT, "bad iteration count");
+  eu_render_params p;
+  if ((rc = build_params(trg, srcs, nsrc, out_dev, out_row_stride_bytes, &p))) return rc;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, g.stream));
+  for (int i = 0; i < iters; i++)
+    if (eu_launch_render(&p, g.stream)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+  HIPCHK(hipEventRecord(e1, g.stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *mean_ms = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return EU_OK;
+}
+
+int eu_hip_malloc(void **p, size_t bytes)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  HIPCHK(hipMalloc(p, bytes));
+  return EU_OK;
+}
+int eu_hip_free(void *p) { if (p) HIPCHK(hipFree(p)); return EU_OK; }
+int eu_hip_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return EU_OK;
+}
+int eu_hip_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return EU_OK;
+}
+
+}  // extern "C"

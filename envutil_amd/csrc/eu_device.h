@@ -1,0 +1,53 @@
+// Structures shared by the host set-up code and the HIP kernels.
+#ifndef EU_DEVICE_H
+#define EU_DEVICE_H
+
+#include <stdint.h>
+#include "../../include/eu_hip.h"
+
+#define EU_LANES 16          // zimt vector width of the pinned reference build
+#define EU_SEGMENT 512       // WIELDING_SEGMENT_SIZE, zimt/bill.h:67-69
+
+// ray = f(column table, row table): the steppers' per-segment invariants
+// (stepper.h) hoisted into tables that the host fills once per target.
+enum { EU_FORM_BCA = 0,      // (B*c0 + C*c1) + A   spherical, cylindrical
+       EU_FORM_BA = 1 };     //  B*c0 + A           rectilinear, cubemap, biatan6
+enum { EU_NORM_NONE = 0, EU_NORM_DIV = 1, EU_NORM_CYL = 2 };
+
+// number of floats per row-table entry: A, B, C for the unbiased and the
+// y-biased stepper
+#define EU_ROW_FLOATS 18
+
+// evaluator + mount parameters of one source, device side
+struct eu_src_dev {
+  const float *base;         // core origin inside the braced container
+  long long es0, es1;        // strides in float elements (eval.h:1865)
+  int prj, nch, degree;
+  int gate0, gate1;          // 0 clamp, 1 mirror, 2 periodic (eval.h:2039-2164)
+  float lower0, upper0, lower1, upper1;
+  // mount_t / source_t (environment.h:970-1006, :1117-1149)
+  double tex_x0, tex_y0;     // total_extent.x0 / .y0 stay double (A.0)
+  float ext_w, ext_h;        // float(x1 - x0), float(y1 - y0)
+  float total_w, total_h;    // float(total_width), float(total_height)
+  float win_x_off, win_y_off;
+  float wex0, wex1, wex2, wex3;  // window extent narrowed for the compares
+  float brighten;
+  // cubemap_view_t (environment.h:1425-1460)
+  float refc_md, model_to_px;
+  int section_px;
+  float wm[(EU_MAX_DEGREE + 1) * (EU_MAX_DEGREE + 1)];  // weight matrix [c][row]
+};
+
+struct eu_render_params {
+  int width, height, row_begin, row_end;
+  int form, norm_mode, twine, ntaps, stage, nch;
+  const float *col;          // [4][width]: c0, c1, c0 (x-biased), c1 (x-biased)
+  const float *row;          // [height][EU_ROW_FLOATS]
+  const float *taps;         // [ntaps][3], x and y already scaled by 4
+  float *out;
+  long long out_stride;      // floats per output row
+  int tiles_x, tiles_y;      // grid of 64x4 tiles
+  eu_src_dev src;
+};
+
+#endif

@@ -1,0 +1,461 @@
+// Set-up stages on the device: what envutil does on the CPU before the render
+// loop can run - b-spline prefilter + bracing of a source image
+// (zimt/prefilter.h, recursive.h, brace.h; environment.h:356-522) and the
+// cubemap "IR" image with its support frame (cubemap.h:576-946).
+//
+// Every 1-D line is filtered by one thread with exactly the float operations of
+// zimt's iir_filter::solve_gain_inlined (recursive.h:631-733); lines are
+// independent, so the grid is "one thread per (line, channel)".
+// Compiled with -ffp-contract=off.
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include "eu_device.h"
+#include "eu_setup_math.h"
+#include "eu_math.h"
+
+namespace {
+
+#define EU_MAX_POLES (EU_MAX_DEGREE / 2 + 1)
+
+struct iir_dev {
+  int bc, npoles;
+  float pole[EU_MAX_POLES];
+  float zpow[EU_MAX_POLES];   // closed-form branches: pole^(M-1) or pole^(2M), in float
+  int horizon[EU_MAX_POLES];
+  float gain;
+};
+
+// recursive.h:790-830 (horizon, gain) - long double on the host
+iir_dev make_iir(int bc, int degree, long double tolerance, long M)
+{
+  iir_dev f;
+  memset(&f, 0, sizeof f);
+  long double lp[EU_MAX_POLES];
+  f.bc = bc;
+  f.npoles = eu::poles(degree, lp);
+  long double gain = 1.0L;
+  for (int k = 0; k < f.npoles; k++) {
+    f.pole[k] = (float)lp[k];
+    f.horizon[k] = tolerance > 0
+      ? (int)ceill(logl(tolerance) / logl(fabsl(lp[k]))) : INT_MAX;
+    gain *= (1.0L - lp[k]) * (1.0L - 1.0L / lp[k]);
+    // icc_natural/icc_mirror use pole^(M-1), icc_reflect pole^(2M), taken in
+    // long double and narrowed (recursive.h:335, :413, :483)
+    long double e = bc == EU_BC_REFLECT ? (long double)(2 * M) : (long double)(M - 1);
+    f.zpow[k] = (float)powl(lp[k], e);
+  }
+  f.gain = (float)gain;
+  return f;
+}
+
+// a line: element n lives at base[off(n)]
+struct strided_line {
+  float *base; long long es;
+  __device__ float get(int n) const { return base[(long long)n * es]; }
+  __device__ void put(int n, float v) const { base[(long long)n * es] = v; }
+};
+
+// environment.h:395-447: column x of the left half top->bottom, then column
+// x + W/2 bottom->top, as one line of length 2H
+struct stacked_line {
+  float *up, *down; long long es; int H;
+  __device__ long long off(int n) const { return n < H ? (long long)n * es : 0; }
+  __device__ float get(int n) const { return n < H ? up[(long long)n * es] : down[(long long)(2 * H - 1 - n) * es]; }
+  __device__ void put(int n, float v) const { if (n < H) up[(long long)n * es] = v; else down[(long long)(2 * H - 1 - n) * es] = v; }
+};
+
+// recursive.h:321-620
+template <class L>
+__device__ float icc(const iir_dev &f, const L &c, int M, int k)
+{
+  float z = f.pole[k], zn, z2n, iz, Sum;
+  int n, hz = f.horizon[k];
+  switch (f.bc) {
+    case EU_BC_NATURAL:
+      if (hz < M) {
+        float c02 = c.get(0) + c.get(0);
+        zn = z; Sum = c.get(0);
+        for (n = 1; n < hz; n++) { Sum = Sum + zn * (c02 - c.get(n)); zn = zn * z; }
+        return Sum;
+      }
+      zn = z; iz = 1.0f / z; z2n = f.zpow[k];
+      Sum = ((1.0f + z) / (1.0f - z)) * (c.get(0) - z2n * c.get(M - 1));
+      z2n = z2n * (z2n * iz);
+      for (n = 1; n <= M - 2; n++) { Sum = Sum - (zn - z2n) * c.get(n); zn = zn * z; z2n = z2n * iz; }
+      return Sum / (1.0f - zn * zn);
+    case EU_BC_REFLECT:
+      if (hz < M) {
+        zn = z; Sum = c.get(0);
+        for (n = 0; n < hz; n++) { Sum = Sum + zn * c.get(n); zn = zn * z; }
+        return Sum;
+      }
+      zn = z; iz = 1.0f / z; z2n = f.zpow[k];
+      Sum = 0.0f;
+      for (n = 0; n < M - 1; n++) { Sum = Sum + (zn + z2n) * c.get(n); zn = zn * z; z2n = z2n * iz; }
+      Sum = Sum + (zn + z2n) * c.get(n);
+      return c.get(0) + Sum / (1.0f - zn * zn);
+    case EU_BC_PERIODIC:
+      if (hz < M) {
+        zn = z; Sum = c.get(0);
+        for (n = M - 1; n > (M - hz); n--) { Sum = Sum + zn * c.get(n); zn = zn * z; }
+      } else {
+        zn = z; Sum = c.get(0);
+        for (n = M - 1; n > 0; n--) { Sum = Sum + zn * c.get(n); zn = zn * z; }
+        Sum = Sum / (1.0f - zn);
+      }
+      return Sum;
+    case EU_BC_MIRROR:
+      if (hz < M) {
+        zn = z; Sum = c.get(0);
+        for (n = 1; n < hz; n++) { Sum = Sum + zn * c.get(n); zn = zn * z; }
+        return Sum;
+      }
+      zn = z; iz = 1.0f / z; z2n = f.zpow[k];
+      Sum = c.get(0) + z2n * c.get(M - 1);
+      z2n = z2n * (z2n * iz);
+      for (n = 1; n <= M - 2; n++) { Sum = Sum + (zn + z2n) * c.get(n); zn = zn * z; z2n = z2n * iz; }
+      return Sum / (1.0f - zn * zn);
+    default:
+      return c.get(0);
+  }
+}
+
+template <class L>
+__device__ float iacc(const iir_dev &f, const L &c, int M, int k)
+{
+  float z = f.pole[k], zn, Sum;
+  int hz = f.horizon[k];
+  switch (f.bc) {
+    case EU_BC_NATURAL:
+      return -(z / ((1.0f - z) * (1.0f - z))) * (c.get(M - 1) - z * c.get(M - 2));
+    case EU_BC_REFLECT:
+      return c.get(M - 1) / (1.0f - 1.0f / z);
+    case EU_BC_PERIODIC:
+      if (hz < M) {
+        zn = z; Sum = c.get(M - 1) * z;
+        for (int n = 0; n < hz; n++) { zn = zn * z; Sum = Sum + zn * c.get(n); }
+        Sum = -Sum;
+      } else {
+        zn = z; Sum = c.get(M - 1);
+        for (int n = 0; n < M - 1; n++) { Sum = Sum + zn * c.get(n); zn = zn * z; }
+        Sum = z * Sum / (zn - 1.0f);
+      }
+      return Sum;
+    case EU_BC_MIRROR:
+      return (z / (z * z - 1.0f)) * (c.get(M - 1) + z * c.get(M - 2));
+    default:
+      return c.get(M - 1);
+  }
+}
+
+// recursive.h:631-733, in place
+template <class L>
+__device__ void solve_line(const iir_dev &f, const L &x, int M)
+{
+  if (M == 1 || f.npoles < 1) return;
+  float p = f.pole[0], g = f.gain;
+  float X = g * icc(f, x, M, 0);
+  x.put(0, X);
+  for (int n = 1; n < M; n++) { X = g * x.get(n) + p * X; x.put(n, X); }
+  X = iacc(f, x, M, 0);
+  x.put(M - 1, X);
+  for (int n = M - 2; n >= 0; n--) { X = p * (X - x.get(n)); x.put(n, X); }
+  for (int k = 1; k < f.npoles; k++) {
+    p = f.pole[k];
+    X = icc(f, x, M, k);
+    x.put(0, X);
+    for (int n = 1; n < M; n++) { X = x.get(n) + p * X; x.put(n, X); }
+    X = iacc(f, x, M, k);
+    x.put(M - 1, X);
+    for (int n = M - 2; n >= 0; n--) { X = p * (X - x.get(n)); x.put(n, X); }
+  }
+}
+
+// lines: nl x nch threads; line i channel c starts at base + i*line_stride + c
+__global__ void filter_lines_kernel(iir_dev f, float *base, long long nl, int nch,
+                                    long long line_stride, int len, long long es)
+{
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nl * nch) return;
+  long long i = t / nch;
+  int c = (int)(t - i * nch);
+  strided_line ln { base + i * line_stride + c, es };
+  solve_line(f, ln, len);
+}
+
+__global__ void filter_stacked_kernel(iir_dev f, float *core, long long half, int nch,
+                                      long long row_es, int H)
+{
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= half * nch) return;   // t = x * nch + c
+  stacked_line ln { core + t, core + t + half * nch, row_es, H };
+  solve_line(f, ln, 2 * H);
+}
+
+// zimt/brace.h:134-330 for one axis; slices span the whole container
+__device__ __forceinline__ long long brace_source(int bc, long long lsz, long long m,
+                                                  long long i, bool left, bool *natural,
+                                                  long long *pivot)
+{
+  long long l0 = lsz - 1, r0 = lsz + m;
+  *natural = false;
+  *pivot = left ? l0 + 1 : r0 - 1;
+  if (m == 1) return lsz;
+  switch (bc) {
+    case EU_BC_PERIODIC: return left ? l0 + m - i : r0 - m + i;
+    case EU_BC_NATURAL:  *natural = true;  /* fall through */
+    case EU_BC_MIRROR:   return left ? l0 + 2 + i : r0 - 2 - i;
+    case EU_BC_REFLECT:  return left ? l0 + 1 + i : r0 - 1 - i;
+    default:             return *pivot;          // CONSTANT
+  }
+}
+
+// axis 0: one thread per (frame column slot, container row, channel)
+__global__ void brace_kernel(float *data, long long sx, long long sy, int nch, int axis,
+                             int bc, long long lsz, long long rsz)
+{
+  const long long len = axis == 0 ? sx : sy, other = axis == 0 ? sy : sx;
+  const long long m = len - lsz - rsz;
+  const long long nframe = lsz + rsz;
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nframe * other * nch) return;
+  int c = (int)(t % nch);
+  long long r = t / nch;
+  long long o, fslot;
+  if (axis == 0) { fslot = r % nframe; o = r / nframe; }
+  else           { o = r % other; fslot = r / other; }
+  bool left = fslot < lsz;
+  long long i = left ? fslot : fslot - lsz;
+  long long target = left ? (lsz - 1 - i) : (lsz + m + i);
+  bool natural; long long pivot;
+  long long src = brace_source(bc, lsz, m, i, left, &natural, &pivot);
+  auto at = [&](long long a) -> float * {
+    return axis == 0 ? data + (o * sx + a) * nch + c : data + (a * sx + o) * nch + c;
+  };
+  if (bc == EU_BC_ZEROPAD && m != 1) { *at(target) = 0.0f; return; }
+  if (natural && m != 1) { float a = *at(pivot), b = *at(src); *at(target) = a + a - b; }
+  else *at(target) = *at(src);
+}
+
+// environment.h:452-516: frame rows above/below a full spherical image come
+// from the opposite meridian
+__global__ void pole_rows_kernel(float *core, long long W, long long H, long long pitch,
+                                 int nch, long long top, long long bottom)
+{
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (top + bottom) * W * nch;
+  if (t >= n) return;
+  int c = (int)(t % nch);
+  long long r = t / nch, x = r % W, k = r / W;
+  long long half = W / 2;
+  long long xs = x < half ? x + half : x - half;
+  long long yt, ys;
+  if (k < top) { yt = -1 - k; ys = k; }
+  else { long long kk = k - top; yt = H + kk; ys = H - 1 - kk; }
+  if (W & 1) return;
+  core[(yt * pitch + x) * nch + c] = core[(ys * pitch + xs) * nch + c];
+}
+
+// ---- cubemap IR ------------------------------------------------------------
+
+__global__ void place_faces_kernel(const float *faces, float *ir, int nch, long long F,
+                                   long long S, long long lf)
+{
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 6 * F * F * nch) return;
+  int c = (int)(t % nch);
+  long long r = t / nch, x = r % F, yy = r / F, f = yy / F, y = yy % F;
+  ir[((f * S + lf + y) * S + lf + x) * nch + c] = faces[t];
+}
+
+// cubemap.h:607-659. The four corner pixels of the ring are written twice in
+// the reference (x loop, then y loop); the second write wins: corner (-1,-1)
+// ends up as a copy of (0,-1), which itself is a copy of (0,0).
+__global__ void mirror_around_kernel(float *ir, int nch, long long F, long long S,
+                                     long long lf, long long rf)
+{
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = F + 2;            // positions -1 .. F
+  if (t >= 6 * 4 * per * nch) return;
+  int c = (int)(t % nch);
+  long long r = t / nch, pos = r % per - 1, side = (r / per) % 4, f = r / (4 * per);
+  int cmin = lf > 0 ? -1 : 0, cmax = rf > 0 ? (int)F : (int)F - 1;
+  if (pos < cmin || pos > cmax) return;
+  float *cf = ir + ((f * S + lf) * S + lf) * nch + c;
+  auto px = [&](long long x, long long y) -> float * { return cf + (y * S + x) * nch; };
+  // sides 0/1: top/bottom rows (x loop); 2/3: left/right columns (y loop).
+  // Corner positions of sides 0/1 are overwritten by sides 2/3, so skip them
+  // there and let the column pass source them from the row the x loop filled.
+  bool corner = pos == -1 || pos == F;
+  switch (side) {
+    case 0: if (lf && !corner) *px(pos, -1) = *px(pos, 0); break;
+    case 1: if (rf && !corner) *px(pos, F) = *px(pos, F - 1); break;
+    case 2:
+      if (lf) {
+        long long sy = pos == -1 ? 0 : (pos == F ? F - 1 : pos);
+        *px(-1, pos) = *px(0, sy);
+      }
+      break;
+    default:
+      if (rf) {
+        long long sy = pos == -1 ? 0 : (pos == F ? F - 1 : pos);
+        *px(F, pos) = *px(F - 1, sy);
+      }
+  }
+}
+
+__device__ __forceinline__ float mirror_gate(float c, float lower, float upper)
+{
+  float cc = c - lower, w = upper - lower;
+  cc = fabsf(cc);
+  if (cc >= w) {
+    float help = cc / (2 * w);
+    help = truncf(help);
+    help = help * (2 * w);
+    float cm = cc - help;
+    if (fabsf(cm) >= fabsf(2 * w)) cm = 0.0f;
+    cm = cm - w;
+    cm = fabsf(cm);
+    cm = w - cm;
+    cc = cm;
+  }
+  return cc + lower;
+}
+
+// fill_frame_t::eval, cubemap.h:724-809, for every frame pixel of one face
+__global__ void fill_frame_kernel(float *ir, int nch, int face, long long F, long long S,
+                                  long long lf, long long rf, double refc_md,
+                                  double model_to_px)
+{
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= S * S) return;
+  long long x = t % S, y = t / S;
+  bool frame = y < lf || y >= S - rf || x < lf || x >= lf + F;
+  if (!frame) return;
+  int ishift = (int)S - 1, ithird = (int)(model_to_px * 2);
+  int ix = (int)(2 * x) - ishift, iy = (int)(2 * y) - ishift;
+  float c3[3];
+  switch (face) {
+    case 4: c3[0] = (float)ix;  c3[1] = (float)iy; c3[2] = (float)ithird; break;
+    case 5: c3[0] = (float)-ix; c3[1] = (float)iy; c3[2] = (float)-ithird; break;
+    case 1: c3[0] = (float)ithird;  c3[1] = (float)iy; c3[2] = (float)-ix; break;
+    case 0: c3[0] = (float)-ithird; c3[1] = (float)iy; c3[2] = (float)ix; break;
+    case 3: c3[0] = (float)-ix; c3[1] = (float)ithird;  c3[2] = (float)iy; break;
+    default: c3[0] = (float)-ix; c3[1] = (float)-ithird; c3[2] = (float)-iy; break;
+  }
+  // ray_to_cubeface, geometry.h:1178-1289
+  float ax = fabsf(c3[0]), ay = fabsf(c3[1]), az = fabsf(c3[2]);
+  bool m1 = ax >= ay, m2 = ax >= az, m3 = ay >= az;
+  int fv; float in0, in1;
+  if (m1 && m2) { fv = c3[0] < 0.0f ? 0 : 1; in0 = -c3[2] / c3[0]; in1 = c3[1] / ax; }
+  else if (!m2 && !m3) { fv = c3[2] < 0.0f ? 5 : 4; in0 = c3[0] / c3[2]; in1 = c3[1] / az; }
+  else { fv = c3[1] < 0.0f ? 2 : 3; in0 = -c3[0] / ay; in1 = c3[2] / c3[1]; }
+  // metrics_t::get_pickup_coordinate_px, cubemap.h:452-464 (double members)
+  float p0 = (float)((double)in0 + refc_md), p1 = (float)((double)in1 + refc_md);
+  p0 = p0 * (float)model_to_px;
+  p1 = p1 * (float)model_to_px;
+  p1 = p1 + (float)(fv * (int)S);
+  p0 = p0 - .5f;
+  p1 = p1 - .5f;
+  // bilinear safe evaluator on the unfiltered IR (shift = 1 - degree):
+  // REFLECT gates over (S, 6S), eval.h:1004-1059
+  float gx = mirror_gate(p0, -0.5f, (float)((long double)(S - 1) + 0.5L));
+  float gy = mirror_gate(p1, -0.5f, (float)((long double)(6 * S - 1) + 0.5L));
+  float fx = floorf(gx), fy = floorf(gy);
+  float tx = gx - fx, ty = gy - fy;
+  const float *p = ir + ((long long)(int)fy * S + (long long)(int)fx) * nch;
+  float wl0 = 1.0f - tx, wr0 = tx, wl1 = 1.0f - ty, wr1 = ty;
+  float *dst = ir + (((long long)face * S + y) * S + x) * nch;
+  for (int c = 0; c < nch; c++) {
+    float sum = p[c] * wl0;
+    sum = sum + p[nch + c] * wr0;
+    sum = sum * wl1;
+    float sub = p[S * nch + c] * wl0;
+    sub = sub + p[S * nch + nch + c] * wr0;
+    sum = sum + sub * wr1;
+    dst[c] = sum;
+  }
+}
+
+inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int nch, int bc0,
+                                   int bc1, int degree, int spherical, void *stream)
+{
+  hipStream_t st = (hipStream_t)stream;
+  const long long W = g->core[0], H = g->core[1], SX = g->shape[0], SY = g->shape[1];
+  float *core = container + ((long long)g->left[1] * SX + g->left[0]) * nch;
+  const int bs = 64;
+  if (spherical) {
+    // environment.h:356-522
+    if (degree > 1) {
+      iir_dev f = make_iir(EU_BC_PERIODIC, degree, 0.0001L, W);
+      hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(H * nch, bs)), dim3(bs), 0, st,
+                         f, core, H, nch, SX * nch, (int)W, (long long)nch);
+      iir_dev f2 = make_iir(EU_BC_PERIODIC, degree, 0.0001L, 2 * H);
+      hipLaunchKernelGGL(filter_stacked_kernel, dim3(blocks_for((W / 2) * nch, bs)), dim3(bs), 0, st,
+                         f2, core, W / 2, nch, SX * nch, (int)H);
+    }
+    long long n = (g->left[1] + g->right[1]) * W * nch;
+    if (n > 0)
+      hipLaunchKernelGGL(pole_rows_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, core, W, H,
+                         SX, nch, (long long)g->left[1], (long long)g->right[1]);
+    long long nb = (g->left[0] + g->right[0]) * SY * nch;
+    if (nb > 0)
+      hipLaunchKernelGGL(brace_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, st, container, SX,
+                         SY, nch, 0, bc0, (long long)g->left[0], (long long)g->right[0]);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  // bspline::prefilter, zimt/bspline.h:1017-1041 + prefilter.h:133-190
+  if (degree > 1) {
+    iir_dev f0 = make_iir(bc0, degree, (long double)FLT_EPSILON, W);
+    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(H * nch, bs)), dim3(bs), 0, st, f0,
+                       core, H, nch, SX * nch, (int)W, (long long)nch);
+    iir_dev f1 = make_iir(bc1, degree, (long double)FLT_EPSILON, H);
+    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(W * nch, bs)), dim3(bs), 0, st, f1,
+                       core, W, nch, (long long)nch, (int)H, SX * nch);
+  }
+  long long nb0 = (g->left[0] + g->right[0]) * SY * nch;
+  if (nb0 > 0)
+    hipLaunchKernelGGL(brace_kernel, dim3(blocks_for(nb0, 256)), dim3(256), 0, st, container, SX,
+                       SY, nch, 0, bc0, (long long)g->left[0], (long long)g->right[0]);
+  long long nb1 = (g->left[1] + g->right[1]) * SX * nch;
+  if (nb1 > 0)
+    hipLaunchKernelGGL(brace_kernel, dim3(blocks_for(nb1, 256)), dim3(256), 0, st, container, SX,
+                       SY, nch, 1, bc1, (long long)g->left[1], (long long)g->right[1]);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int eu_launch_cubemap_build(const float *faces, float *ir, int nch, long F, long S,
+                                       long lf, long rf, double refc_md, double model_to_px,
+                                       int prefilter_degree, void *stream)
+{
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(place_faces_kernel, dim3(blocks_for(6LL * F * F * nch, 256)), dim3(256), 0,
+                     st, faces, ir, nch, (long long)F, (long long)S, (long long)lf);
+  if (lf || rf) {
+    hipLaunchKernelGGL(mirror_around_kernel, dim3(blocks_for(6LL * 4 * (F + 2) * nch, 256)),
+                       dim3(256), 0, st, ir, nch, (long long)F, (long long)S, (long long)lf,
+                       (long long)rf);
+    for (int face = 0; face < 6; face++)
+      hipLaunchKernelGGL(fill_frame_kernel, dim3(blocks_for((long long)S * S, 256)), dim3(256), 0,
+                         st, ir, nch, face, (long long)F, (long long)S, (long long)lf,
+                         (long long)rf, refc_md, model_to_px);
+  }
+  if (prefilter_degree > 1) {
+    // cubemap.h:921-946: per section, NATURAL x NATURAL, default tolerance
+    iir_dev f = make_iir(EU_BC_NATURAL, prefilter_degree, (long double)FLT_EPSILON, S);
+    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(6LL * S * nch, 64)), dim3(64), 0, st, f,
+                       ir, 6LL * S, nch, (long long)S * nch, (int)S, (long long)nch);
+    for (int face = 0; face < 6; face++)
+      hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for((long long)S * nch, 64)), dim3(64), 0,
+                         st, f, ir + (long long)face * S * S * nch, (long long)S, nch,
+                         (long long)nch, (int)S, (long long)S * nch);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,454 @@
+// Host-side set-up arithmetic of the render path: everything envutil computes
+// once per job on the CPU before zimt::process runs. Plain C++, no HIP.
+// Each function names the reference lines it stands in for.
+#ifndef EU_SETUP_MATH_H
+#define EU_SETUP_MATH_H
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "eu_device.h"
+
+namespace eu {
+
+// ---- extents: envutil_basic.cc:49-229 -------------------------------------
+
+inline double get_vfov(int prj, int width, int height, double hfov)
+{
+  switch (prj) {
+    case EU_RECTILINEAR:
+      return 2.0 * std::atan(height * std::tan(hfov / 2.0) / width);
+    case EU_CYLINDRICAL: {
+      double pixels_per_rad = width / hfov;
+      double h_rad = height / pixels_per_rad;
+      return 2.0 * std::atan(h_rad / 2.0);
+    }
+    case EU_STEREOGRAPHIC: {
+      double w_rad = 2.0 * std::tan(hfov / 4.0);
+      double pixels_per_rad = width / w_rad;
+      double h_rad = height / pixels_per_rad;
+      return 4.0 * std::atan(h_rad / 2.0);
+    }
+    case EU_SPHERICAL:
+    case EU_FISHEYE:
+      return hfov * height / width;
+    default:
+      return hfov;   // cubemap/biatan6 fall through to this in the reference
+  }
+}
+
+inline double get_step(int prj, int width, int /*height*/, double hfov)
+{
+  switch (prj) {
+    case EU_RECTILINEAR:
+    case EU_CUBEMAP:
+      return std::atan(2.0 * std::tan(hfov / 2.0) / width);
+    case EU_BIATAN6:
+    case EU_SPHERICAL:
+    case EU_CYLINDRICAL:
+    case EU_FISHEYE:
+      return hfov / width;
+    case EU_STEREOGRAPHIC:
+      return std::atan(4.0 * std::tan(hfov / 4.0) / width);
+  }
+  return 0.0;
+}
+
+inline void get_extent(int prj, int width, int height, double hfov, double *e)
+{
+  double ax = -hfov / 2.0, bx = hfov / 2.0;
+  double by = get_vfov(prj, width, height, hfov) / 2.0, ay = -by;
+  double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+  switch (prj) {
+    case EU_SPHERICAL:
+    case EU_FISHEYE: x0 = ax; x1 = bx; y0 = ay; y1 = by; break;
+    case EU_CYLINDRICAL: x0 = ax; x1 = bx; y0 = std::tan(ay); y1 = std::tan(by); break;
+    case EU_RECTILINEAR:
+      x0 = std::tan(ax); x1 = std::tan(bx); y0 = std::tan(ay); y1 = std::tan(by); break;
+    case EU_STEREOGRAPHIC:
+      x0 = 2.0 * std::tan(ax / 2.0); x1 = 2.0 * std::tan(bx / 2.0);
+      y0 = 2.0 * std::tan(ay / 2.0); y1 = 2.0 * std::tan(by / 2.0); break;
+    case EU_CUBEMAP:
+    case EU_BIATAN6:
+      x0 = std::tan(ax); x1 = std::tan(bx); y0 = 6 * x0; y1 = 6 * x1; break;
+  }
+  e[0] = x0; e[1] = x1; e[2] = y0; e[3] = y1;
+}
+
+// ---- orientation: envutil_payload.cc:136-218, geometry.h:74-97 ------------
+// Imath (not part of the reference tree) supplies Eulerf(roll, pitch, yaw,
+// ZXY).toQuat(), Quat::invert and Vec3 * Quat; this follows Imath 3's
+// ImathEuler.h / ImathQuat.h for that order (static frame, even parity,
+// first axis Z: i = 2, j = 0, k = 1).
+
+struct mat3 { double m[9]; };
+
+inline mat3 make_r3(double roll, double pitch, double yaw, bool inverse)
+{
+  float ax = (float)roll, ay = (float)pitch, az = (float)yaw;
+  float ti = (float)(ax * 0.5), tj = (float)(ay * 0.5), th = (float)(az * 0.5);
+  float ci = std::cos(ti), cj = std::cos(tj), ch = std::cos(th);
+  float si = std::sin(ti), sj = std::sin(tj), sh = std::sin(th);
+  float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+  float a[3];
+  a[2] = cj * sc - sj * cs;
+  a[0] = (float)((cj * ss + sj * cc) * 1.0);
+  a[1] = cj * cs - sj * sc;
+  float qr = cj * cc + sj * ss;
+  double r = qr, v[3] = { a[0], a[1], a[2] };
+  if (inverse) {
+    double qdot = r * r + (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    r /= qdot;
+    for (int i = 0; i < 3; i++) v[i] = -v[i] / qdot;
+  }
+  auto cross = [](const double *p, const double *q, double *o) {
+    o[0] = p[1] * q[2] - p[2] * q[1];
+    o[1] = p[2] * q[0] - p[0] * q[2];
+    o[2] = p[0] * q[1] - p[1] * q[0];
+  };
+  mat3 out;
+  for (int e = 0; e < 3; e++) {
+    double in[3] = { 0, 0, 0 }, A[3], B[3];
+    in[e] = 1.0;
+    cross(v, in, A);
+    cross(v, A, B);
+    for (int i = 0; i < 3; i++) out.m[3 * e + i] = in[i] + 2.0 * (r * A[i] + B[i]);
+  }
+  return out;
+}
+
+inline mat3 rotate(const mat3 &l, const mat3 &r)
+{
+  mat3 o;
+  for (int row = 0; row < 3; row++)
+    for (int i = 0; i < 3; i++)
+      o.m[3 * row + i] = (l.m[3 * row] * r.m[i] + l.m[3 * row + 1] * r.m[3 + i])
+                         + l.m[3 * row + 2] * r.m[6 + i];
+  return o;
+}
+
+// ---- twining taps: envutil_main.cc:1253-1355 -------------------------------
+
+inline int make_spread(int w, int h, float d, float sigma, float threshold,
+                       std::vector<float> &out)
+{
+  if (w <= 2) w = 2;
+  if (h <= 0) h = w;
+  float wgt = (float)(1.0 / (w * h));
+  double x0 = -(w - 1.0) / (2.0 * w), dx = 1.0 / w;
+  double y0 = -(h - 1.0) / (2.0 * h), dy = 1.0 / h;
+  out.clear();
+  sigma = (float)(sigma * -x0);
+  double sum = 0.0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float wf = 1.0f;
+      if (sigma > 0.0) {
+        double wx = (x0 + x * dx) / sigma, wy = (y0 + y * dy) / sigma;
+        wf = (float)std::exp(-std::sqrt(wx * wx + wy * wy));
+      }
+      out.push_back((float)(d * (x0 + x * dx)));
+      out.push_back((float)(d * (y0 + y * dy)));
+      out.push_back(wf * wgt);
+      sum += wf * wgt;
+    }
+  if (sigma != 0.0) {
+    double th_sum = 0.0;
+    bool renorm = false;
+    for (size_t i = 2; i < out.size(); i += 3) {
+      out[i] = (float)(out[i] / sum);
+      if (out[i] >= threshold) th_sum += out[i];
+      else { renorm = true; out[i] = 0.0f; }
+    }
+    if (renorm) {
+      std::vector<float> keep;
+      for (size_t i = 0; i < out.size(); i += 3) {
+        float wv = (float)(out[i + 2] / th_sum);
+        if (wv > 0.0f) { keep.push_back(out[i]); keep.push_back(out[i + 1]); keep.push_back(wv); }
+      }
+      out.swap(keep);
+    }
+  }
+  return (int)(out.size() / 3);
+}
+
+// ---- cubemap geometry: metrics_t, cubemap.h:233-400 ------------------------
+
+struct metrics {
+  long face_px, section_px, left_frame_px, right_frame_px;
+  double model_to_px, px_to_model, section_md, refc_md;
+};
+
+inline metrics make_metrics(long face_px, double face_fov, long support_min, long tile_px)
+{
+  metrics m;
+  double overscan_md = 0.0, diameter_md = 2.0;
+  m.face_px = face_px;
+  if (face_fov > M_PI_2) {
+    double radius_md = std::tan(face_fov / 2.0);
+    diameter_md = 2.0 * radius_md;
+    overscan_md = radius_md - 1.0;
+  }
+  m.model_to_px = double(face_px) / diameter_md;
+  m.px_to_model = diameter_md / double(face_px);
+  long inherent = (long)std::trunc(m.model_to_px * overscan_md);
+  long additional = inherent < support_min ? support_min - inherent : 0;
+  long px_min = face_px + 2 * additional;
+  long n_tiles = px_min / tile_px;
+  if (n_tiles * tile_px < px_min) n_tiles++;
+  m.section_px = n_tiles * tile_px;
+  long frame_total = m.section_px - face_px;
+  m.left_frame_px = frame_total / 2;
+  m.right_frame_px = frame_total - m.left_frame_px;
+  m.section_md = m.px_to_model * m.section_px;
+  m.refc_md = m.px_to_model * (double(m.left_frame_px) + double(face_px) / 2.0);
+  return m;
+}
+
+// ---- b-spline container geometry: zimt/bspline.h:305-450 -------------------
+
+inline long left_brace(int degree, int bc)
+{
+  long n = degree / 2;
+  if (bc == EU_BC_REFLECT) n++;
+  else if (degree & 1) n++;
+  if (bc == EU_BC_PERIODIC && !(degree & 1)) n++;
+  return n;
+}
+
+inline long right_brace(int degree, int bc)
+{
+  long n = degree / 2;
+  if (bc == EU_BC_REFLECT && !(degree & 1)) n++;
+  if (degree & 1) n++;
+  if (bc == EU_BC_PERIODIC) n++;
+  return n;
+}
+
+inline void container_geometry(int degree, int bc0, int bc1, int64_t w, int64_t h,
+                               eu_container *g)
+{
+  g->left[0] = left_brace(degree, bc0);  g->left[1] = left_brace(degree, bc1);
+  g->right[0] = right_brace(degree, bc0); g->right[1] = right_brace(degree, bc1);
+  g->core[0] = w; g->core[1] = h;
+  g->shape[0] = w + g->left[0] + g->right[0];
+  g->shape[1] = h + g->left[1] + g->right[1];
+}
+
+// ---- basis: weight matrix (zimt/basis.h:419-545), poles (zimt/poles.h) -----
+
+// centred B-spline of degree n at x2/2, exact rational evaluated in long double
+inline long double basis_half(int x2, int n)
+{
+  if (n == 0) return (x2 == -1 || x2 == 0) ? 1.0L : 0.0L;
+  int ax = x2 < 0 ? -x2 : x2;
+  if (ax > n) return 0.0L;
+  long double acc = 0.0L, binom = 1.0L;
+  for (int k = 0; k <= n + 1; k++) {
+    long double t = (long double)(ax - 2 * k + (n + 1));
+    if (t > 0) {
+      long double p = 1.0L;
+      for (int i = 0; i < n; i++) p *= t;
+      acc += ((k & 1) ? -binom : binom) * p;
+    }
+    binom = binom * (long double)(n + 1 - k) / (long double)(k + 1);
+  }
+  long double den = 1.0L;
+  for (int i = 2; i <= n; i++) den *= i;
+  for (int i = 0; i < n; i++) den *= 2.0L;
+  return acc / den;
+}
+
+// m[c * (degree+1) + row]: Taylor coefficient 'row' of the polynomial piece
+// that weights tap c
+inline void weight_matrix(int degree, float *m)
+{
+  const int order = degree + 1;
+  long double line[EU_MAX_DEGREE + 2];
+  long double faculty = 1.0L;
+  for (int row = 0; row < order; row++) {
+    if (row > 1) faculty *= row;
+    long double *first = line, *end = line + degree + 1;
+    int mm = degree - row;
+    if (mm == 0) { line[0] = 1.0L; first++; }
+    else if (degree & 1)
+      for (int x2 = -mm + 1; x2 <= mm - 1; x2 += 2) *first++ = basis_half(x2, mm);
+    else
+      for (int x2 = -mm; x2 <= mm; x2 += 2) *first++ = basis_half(x2, mm);
+    for (long double *p = first; p < end; p++) *p = 0.0L;
+    for (int d = mm; d < degree; d++) {
+      long double *put = first, *pick = put - 1;
+      while (pick >= line) { *put = *pick - *put; --put; --pick; }
+      *put = -*put;
+      first++;
+    }
+    for (int k = 0; k <= degree; k++) m[k * order + row] = (float)(line[k] / faculty);
+  }
+}
+
+// prefilter poles: the degree/2 roots in (-1, 0) of sum_k beta^n(k) z^(k+n/2),
+// most negative first
+inline int poles(int degree, long double *out)
+{
+  int np = degree / 2;
+  if (np == 0) return 0;
+  int len = 2 * np + 1;
+  long double c[2 * EU_MAX_DEGREE + 3];
+  for (int k = -np; k <= np; k++) c[k + np] = basis_half(2 * k, degree);
+  auto ev = [&](long double z, long double *dp) {
+    long double p = c[len - 1], d = 0.0L;
+    for (int i = len - 2; i >= 0; i--) { d = d * z + p; p = p * z + c[i]; }
+    if (dp) *dp = d;
+    return p;
+  };
+  int found = 0;
+  long double za = -1.0L, pa = ev(za, nullptr);
+  while (found < np && za < -1e-12L) {
+    long double zb = za * 0.9L, pb = ev(zb, nullptr);
+    if ((pa < 0) != (pb < 0)) {
+      long double lo = za, hi = zb, plo = pa;
+      for (int it = 0; it < 90; it++) {
+        long double mid = 0.5L * (lo + hi), pm = ev(mid, nullptr);
+        if ((pm < 0) == (plo < 0)) { lo = mid; plo = pm; } else hi = mid;
+      }
+      long double z = 0.5L * (lo + hi);
+      for (int it = 0; it < 4; it++) { long double dp, p = ev(z, &dp); z -= p / dp; }
+      out[found++] = z;
+    }
+    za = zb; pa = pb;
+  }
+  return found;
+}
+
+// ---- stepper tables: stepper.h:294-350 and the per-projection init() --------
+
+struct stepper_tables {
+  int form, norm_mode;
+  std::vector<float> col;     // [4][W]
+  std::vector<float> row;     // [H][EU_ROW_FLOATS]
+};
+
+// planar x of every column, with the accumulation the reference performs:
+// segment-start value of the pixel's lane plus k additions of delta
+inline void planar_columns(int W, float a0, float a1, float bias, float *out)
+{
+  float fx1 = (float)(a1 / (2.0 * W));
+  float fx0 = (float)(a0 / (2.0 * W));
+  float bias_x = bias * (a1 - a0) / (float)W;
+  float delta = (float)EU_LANES * (a1 - a0) / (float)W;
+  for (int seg = 0; seg < W; seg += EU_SEGMENT)
+    for (int lane = 0; lane < EU_LANES && seg + lane < W; lane++) {
+      float ll0 = (float)(2 * lane) + (float)(seg * 2 + 1);
+      float p = bias_x + ll0 * fx1 + ((float)(2 * W) - ll0) * fx0;
+      for (int x = seg + lane; x < W && x < seg + EU_SEGMENT; x += EU_LANES) {
+        out[x] = p;
+        p += delta;
+      }
+    }
+}
+
+inline float planar_row(int H, float b0, float b1, float bias, int y)
+{
+  float fy1 = (float)(b1 / (2.0 * H));
+  float fy0 = (float)(b0 / (2.0 * H));
+  float bias_y = bias * (b1 - b0) / (float)H;
+  int ll1 = y * 2 + 1;
+  return bias_y + ll1 * fy1 + (float)(2 * H - ll1) * fy0;
+}
+
+// Fills the tables for one target. `normalize` is the stepper template flag:
+// false for single-facet rendering without twining, true otherwise
+// (envutil_payload.cc:2118, :2227). Returns false for projections whose
+// stepper needs per-pixel transcendentals (fisheye, stereographic).
+inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool normalize,
+                                 bool twine, stepper_tables &tb)
+{
+  const int W = t.width, H = t.height, prj = t.projection;
+  const float a0 = (float)t.x0, a1 = (float)t.x1, b0 = (float)t.y0, b1 = (float)t.y1;
+  float xx[3], yy[3], zz[3];
+  for (int i = 0; i < 3; i++) { xx[i] = (float)basis.m[i]; yy[i] = (float)basis.m[3 + i]; zz[i] = (float)basis.m[6 + i]; }
+  tb.col.assign((size_t)4 * W, 0.0f);
+  tb.row.assign((size_t)H * EU_ROW_FLOATS, 0.0f);
+  std::vector<float> p0((size_t)W), p0b((size_t)W);
+  planar_columns(W, a0, a1, 0.0f, p0.data());
+  if (twine) planar_columns(W, a0, a1, 0.25f, p0b.data());
+  const float section_md = a1 - a0, refc_md = (float)((a1 - a0) / 2.0);
+  const float q = (float)(M_PI / 4.0);
+  tb.norm_mode = EU_NORM_NONE;
+  switch (prj) {
+    case EU_SPHERICAL:
+    case EU_CYLINDRICAL:
+      tb.form = EU_FORM_BCA;
+      if (prj == EU_CYLINDRICAL && normalize) tb.norm_mode = EU_NORM_CYL;
+      for (int x = 0; x < W; x++) {
+        tb.col[x] = std::sin(p0[x]);
+        tb.col[(size_t)W + x] = std::cos(p0[x]);
+        if (twine) {
+          tb.col[(size_t)2 * W + x] = std::sin(p0b[x]);
+          tb.col[(size_t)3 * W + x] = std::cos(p0b[x]);
+        }
+      }
+      break;
+    case EU_RECTILINEAR:
+    case EU_CUBEMAP:
+      tb.form = EU_FORM_BA;
+      if (normalize) tb.norm_mode = EU_NORM_DIV;
+      for (int x = 0; x < W; x++) {
+        tb.col[x] = p0[x];
+        if (twine) tb.col[(size_t)2 * W + x] = p0b[x];
+      }
+      break;
+    case EU_BIATAN6:
+      tb.form = EU_FORM_BA;
+      if (normalize) tb.norm_mode = EU_NORM_DIV;
+      for (int x = 0; x < W; x++) {
+        tb.col[x] = std::tan(p0[x] * q);
+        if (twine) tb.col[(size_t)2 * W + x] = std::tan(p0b[x] * q);
+      }
+      break;
+    default:
+      return false;
+  }
+  for (int y = 0; y < H; y++) {
+    for (int v = 0; v < (twine ? 2 : 1); v++) {
+      float p1 = planar_row(H, b0, b1, v ? 0.25f : 0.0f, y);
+      float *r = &tb.row[(size_t)y * EU_ROW_FLOATS + 9 * v];   // A, B, C
+      switch (prj) {
+        case EU_SPHERICAL: {     // stepper.h:605-667
+          float sy = std::sin(p1), rr = std::cos(p1);
+          for (int i = 0; i < 3; i++) { r[3 + i] = xx[i] * rr; r[i] = yy[i] * sy; r[6 + i] = zz[i] * rr; }
+          break;
+        }
+        case EU_CYLINDRICAL:     // stepper.h:760-800
+          for (int i = 0; i < 3; i++) { r[3 + i] = xx[i]; r[i] = yy[i] * p1; r[6 + i] = zz[i]; }
+          break;
+        case EU_RECTILINEAR:     // stepper.h:895-932
+          for (int i = 0; i < 3; i++) { r[3 + i] = xx[i]; r[i] = yy[i] * p1 + zz[i]; }
+          break;
+        default: {               // cubemap, biatan6: stepper.h:1274-1358, :1449-1560
+          int face = y / W;
+          float pp = p1 + (float)(3 - face) * section_md - refc_md;
+          if (prj == EU_BIATAN6) pp = std::tan(pp * q);
+          for (int i = 0; i < 3; i++) {
+            float ccc, vvv;
+            switch (face) {
+              case 0: ccc = (float)(-1.0 * (double)xx[i] + (double)(pp * yy[i])); vvv = zz[i]; break;
+              case 1: ccc = (float)(1.0 * (double)xx[i] + (double)(pp * yy[i])); vvv = -zz[i]; break;
+              case 2: ccc = (float)(-1.0 * (double)yy[i] - (double)(pp * zz[i])); vvv = -xx[i]; break;
+              case 3: ccc = (float)(1.0 * (double)yy[i] + (double)(pp * zz[i])); vvv = -xx[i]; break;
+              case 4: ccc = (float)((double)(pp * yy[i]) + 1.0 * (double)zz[i]); vvv = xx[i]; break;
+              default: ccc = (float)((double)(pp * yy[i]) - 1.0 * (double)zz[i]); vvv = -xx[i]; break;
+            }
+            r[i] = ccc;
+            r[3 + i] = vvv;
+          }
+        }
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace eu
+#endif

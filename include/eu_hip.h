@@ -1,0 +1,167 @@
+/* eu_hip.h - C ABI of the MI355X-native envutil reprojection path.
+ *
+ * This is the drop-in boundary for ONE path of kfjahnke/envutil: the
+ * per-output-pixel reprojection that the reference runs as
+ *   zimt::process(trg.shape, get, act, cstor, bill)      envutil_payload.cc:541
+ * behind
+ *   dispatch_base::payload(nchannels, ninputs, projection) envutil_dispatch.h:49-65
+ * Everything here is plain C: pointers, sizes, PODs. No torch types, no C++.
+ * A reference maintainer binds it exactly where the per-ISA `dispatch` structs
+ * are built today (envutil_payload.cc:2390-2442); INTEGRATION.md shows the stub.
+ *
+ * Conventions: axes RIGHT, DOWN, FORWARD; cube faces
+ * LEFT0 RIGHT1 TOP2 BOTTOM3 FRONT4 BACK5 stacked vertically; angles in radians;
+ * pixels are interleaved float32 channels, x fastest, rows contiguous.
+ *
+ * All functions return 0 on success or a negative eu_status code; none of them
+ * aborts. eu_hip_last_error() gives the text for the calling thread.
+ */
+#ifndef EU_HIP_H
+#define EU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mirrors projection_t, envutil_basic.h:68-78 */
+typedef enum {
+  EU_SPHERICAL = 0, EU_CYLINDRICAL, EU_RECTILINEAR, EU_STEREOGRAPHIC,
+  EU_FISHEYE, EU_CUBEMAP, EU_BIATAN6, EU_PRJ_NONE
+} eu_projection;
+
+/* mirrors zimt::bc_code, zimt/common.h:82-91 */
+typedef enum {
+  EU_BC_MIRROR = 0, EU_BC_PERIODIC, EU_BC_REFLECT, EU_BC_NATURAL,
+  EU_BC_CONSTANT, EU_BC_ZEROPAD, EU_BC_GUESS
+} eu_bc;
+
+typedef enum {
+  EU_OK = 0,
+  EU_ERR_NO_DEVICE = -1,     /* no HIP device / HIP runtime error            */
+  EU_ERR_ARGUMENT = -2,      /* inconsistent or out-of-range argument        */
+  EU_ERR_UNSUPPORTED = -3,   /* valid for the reference, not built yet here  */
+  EU_ERR_MEMORY = -4,
+  EU_ERR_HANDLE = -5
+} eu_status;
+
+#define EU_MAX_DEGREE 9
+#define EU_MAX_TAPS 1024
+#define EU_MAX_FACETS 64
+
+/* One source image. Mirrors the fields of facet_spec / facet_base that the
+ * render path reads (envutil_basic.h:432-520). `step`, `brighten` as there. */
+typedef struct eu_facet {
+  int32_t projection;            /* eu_projection                              */
+  int32_t nchannels;             /* 1..4                                       */
+  double  hfov;                  /* radians                                    */
+  int32_t width, height;         /* total size; cubemaps: face width, height=6w*/
+  int32_t window_width, window_height, window_x_offset, window_y_offset;
+  double  yaw, pitch, roll;      /* radians                                    */
+  double  brighten;              /* facet_spec::brighten                       */
+  double  step;                  /* facet_base::step (get_step)                */
+  int32_t has_lcp;               /* lens polynomial / shift / shear present    */
+  double  a, b, c, h, v, s, shear_g, shear_t;
+} eu_facet;
+
+typedef struct eu_source eu_source;   /* opaque: coefficients resident in HBM */
+
+/* Geometry of a braced b-spline container as zimt::bspline lays it out
+ * (zimt/bspline.h:305-450, :759-820); filled by eu_hip_container_geometry. */
+typedef struct eu_container {
+  int64_t shape[2];              /* container shape, pixels                    */
+  int64_t left[2], right[2];     /* frame widths                               */
+  int64_t core[2];               /* core shape                                 */
+} eu_container;
+
+/* The target image and job parameters that travel in envutil's global `args`
+ * (envutil_basic.h:633-705): extent as computed by get_extent
+ * (envutil_basic.cc:156-229), camera orientation, twining tap table as
+ * produced by make_spread (envutil_main.cc:1253-1355; ntaps = 0: ninputs 3). */
+typedef struct eu_target {
+  int32_t projection;
+  int32_t width, height;
+  double  x0, x1, y0, y1;
+  double  yaw, pitch, roll;
+  int32_t nchannels;
+  int32_t ntaps;
+  const float *taps;             /* host pointer, ntaps x {x, y, weight}       */
+  int32_t row_begin, row_end;    /* rows [row_begin,row_end): multi-GPU tiling */
+  int32_t stage;                 /* 0 pixels; 1 rays; 2 source coordinates
+                                    (stages 1/2 write 3 floats per pixel; used
+                                    by the stage-wise parity tests)            */
+} eu_target;
+
+/* ---- device / lifecycle ------------------------------------------------- */
+int  eu_hip_device_count(void);
+int  eu_hip_init(int device);                 /* selects the device for this process */
+const char *eu_hip_last_error(void);
+
+/* ---- set-up arithmetic shared with the reference's host code ------------- */
+/* get_extent / get_vfov / get_step, envutil_basic.cc:49-229 */
+int  eu_hip_get_extent(int projection, int width, int height, double hfov,
+                       double *x0x1y0y1);
+double eu_hip_get_step(int projection, int width, int height, double hfov);
+/* make_spread, envutil_main.cc:1253-1355; returns tap count or <0 */
+int  eu_hip_make_spread(int w, int h, float d, float sigma, float threshold,
+                        float *taps, int max_taps);
+/* metrics_t, cubemap.h:233-400: section_px, left/right frame, refc_md, model_to_px */
+int  eu_hip_cubemap_metrics(int face_px, double face_fov, int support_min,
+                            int tile_px, int64_t *section_px,
+                            int64_t *left_frame_px, double *refc_md,
+                            double *model_to_px);
+int  eu_hip_container_geometry(int degree, int bc0, int bc1, int64_t w,
+                               int64_t h, eu_container *out);
+
+/* ---- sources: the asset_handler residency (environment.h:84-227) --------- */
+/* Load pixel data (host pointer, window_width x window_height interleaved
+ * floats; cubemaps: 6 stacked faces), build the braced coefficient container
+ * in HBM and prefilter it ON THE DEVICE, as source_t's constructor
+ * (environment.h:594-962) or cubemap_t::load (cubemap.h:1147-1233) do on the
+ * CPU. */
+int  eu_hip_source_load(const eu_facet *fct, const float *pixels,
+                        int spline_degree, int prefilter_degree,
+                        int support_min, int tile_size, eu_source **out);
+/* Adopt an already prefiltered and braced container (host pointer, shape as
+ * eu_hip_container_geometry reports; cubemaps: the IR image section_px x
+ * 6*section_px). This is what a bound reference hands over when it keeps its
+ * own set-up stage. */
+int  eu_hip_source_adopt(const eu_facet *fct, const float *container,
+                         int spline_degree, int bc0, int bc1,
+                         int support_min, int tile_size, eu_source **out);
+/* copy the device-resident container back (tests, checkpointing) */
+int  eu_hip_source_download(const eu_source *src, float *container,
+                            size_t nfloats);
+int  eu_hip_source_info(const eu_source *src, eu_container *geom, int *nch);
+int  eu_hip_source_release(eu_source *src);
+
+/* ---- the hot path --------------------------------------------------------- */
+/* zimt::process(shape, stepper, environment|twine_t, storer): renders rows
+ * [row_begin,row_end) of the target into `out` (row stride in bytes).
+ * out_on_device != 0: `out` is a device pointer, the call is asynchronous on
+ * `stream` (a hipStream_t, NULL = the library's own stream) until
+ * eu_hip_sync(); otherwise `out` is host memory and the call returns when the
+ * rows are there. */
+int  eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc,
+                   float *out, size_t out_row_stride_bytes, int out_on_device,
+                   void *stream);
+int  eu_hip_sync(void);
+
+/* Time the render kernel alone with HIP events on its own stream: runs the
+ * launch `iters` times back to back, returns the mean kernel duration. */
+int  eu_hip_render_timed(const eu_target *trg, eu_source *const *srcs, int nsrc,
+                         float *out_dev, size_t out_row_stride_bytes,
+                         int iters, float *mean_ms);
+
+/* device memory helpers for hosts without a HIP binding of their own */
+int  eu_hip_malloc(void **p, size_t bytes);
+int  eu_hip_free(void *p);
+int  eu_hip_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int  eu_hip_memcpy_h2d(void *dst, const void *src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+"""Shared job construction for the parity tests: one description drives both
+the CPU oracle (tests/euo.py) and the HIP library (envutil_amd). TEST CODE."""
+import ctypes as C
+import math
+
+import numpy as np
+
+import euo
+
+
+def synth_image(w, h, nch, seed=12345):
+    """smooth field + mild LCG noise, deterministic."""
+    x = np.arange(w, dtype=np.float64)[None, :]
+    y = np.arange(h, dtype=np.float64)[:, None]
+    out = np.zeros((h, w, nch), np.float32)
+    for c in range(nch):
+        if nch in (2, 4) and c == nch - 1:
+            out[:, :, c] = 1.0
+            continue
+        smooth = 0.5 + 0.25 * np.sin(2 * np.pi * (3 + c) * x / w) * np.cos(2 * np.pi * (2 + c) * y / h)
+        n = w * h
+        # lcg(seed + c; a=1664525, c=1013904223), one step per pixel index
+        idx = (np.arange(n, dtype=np.uint64) + np.uint64(1))
+        state = (np.uint64(seed + c) + idx * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+        state = (state * np.uint64(1664525) + np.uint64(1013904223)) & np.uint64(0xFFFFFFFF)
+        noise = ((state >> np.uint64(8)).astype(np.float64) / float(1 << 24)).reshape(h, w)
+        out[:, :, c] = (smooth + 0.05 * noise - 0.025).astype(np.float32)
+    return out
+
+
+def synth_cubefaces(face, nch, seed=777):
+    return synth_image(face, 6 * face, nch, seed)
+
+
+def source_bcs(prj, hfov_rad):
+    bc0 = euo.REFLECT
+    if prj in (euo.SPHERICAL, euo.CYLINDRICAL) and abs(hfov_rad - 2 * math.pi) < 1e-6:
+        bc0 = euo.PERIODIC
+    return bc0, euo.REFLECT
+
+
+class OracleSource:
+    """source_t / cubemap_t set-up on the CPU oracle (environment.h:594-962,
+    cubemap.h:1147-1233) -> euo.Source"""
+
+    def __init__(self, prj, width, height, hfov_deg, pixels, spline_degree,
+                 prefilter_degree=None, yaw=0.0, pitch=0.0, roll=0.0, brighten=1.0,
+                 support_min=8, tile=64):
+        if prefilter_degree is None:
+            prefilter_degree = spline_degree
+        hf = math.radians(hfov_deg)
+        pixels = np.ascontiguousarray(pixels, np.float32)
+        nch = pixels.shape[2]
+        s = euo.Source()
+        s.projection = prj
+        s.hfov = hf
+        s.width, s.height = width, height
+        s.window_width, s.window_height = width, height
+        s.yaw, s.pitch, s.roll = (math.radians(v) for v in (yaw, pitch, roll))
+        s.brighten = brighten
+        s.step = euo.lib().euo_get_step(prj, width, height, hf)
+        if prj in (euo.CUBEMAP, euo.BIATAN6):
+            m, ir = euo.cubemap_build(pixels, spline_degree, prefilter_degree, hf,
+                                      support_min, tile)
+            self.container = ir
+            sp = euo.Spline()
+            sp.data = ir.ctypes.data_as(C.POINTER(C.c_float))
+            sp.shape[0], sp.shape[1] = m.section_px, 6 * m.section_px
+            sp.stride[0], sp.stride[1] = 1, m.section_px
+            sp.core[0], sp.core[1] = m.section_px, 6 * m.section_px
+            sp.bc[0] = sp.bc[1] = euo.REFLECT
+            sp.degree = spline_degree
+            sp.nch = nch
+            s.spl = sp
+            s.refc_md = np.float32(m.refc_md)
+            s.model_to_px = np.float32(m.model_to_px)
+            s.section_px = m.section_px
+            self.bc = (euo.REFLECT, euo.REFLECT)
+        else:
+            bc0, bc1 = source_bcs(prj, hf)
+            b = euo.BSpline(pixels, spline_degree, bc0, bc1)
+            if prj == euo.SPHERICAL and abs(hf - 2 * math.pi) < 1e-6 and width == 2 * height:
+                b.spherical_prefilter(prefilter_degree)
+            else:
+                b.prefilter(prefilter_degree)
+            self.bspline = b
+            self.container = b.container
+            s.spl = b.s
+            self.bc = (bc0, bc1)
+        self.s = s
+        self.nch = nch
+        self.degree = spline_degree
+
+
+def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8):
+    """args: envutil_amd.arguments (only its plain fields are read)"""
+    j = euo.Job()
+    j.projection = args.projection
+    j.width, j.height = args.width, args.height
+    j.x0, j.x1, j.y0, j.y1 = (float(v) for v in args.extent)
+    j.yaw, j.pitch, j.roll = (math.radians(v) for v in (args.yaw, args.pitch, args.roll))
+    j.nch = osrc.nch
+    taps = None
+    if args.twine_spread is not None:
+        taps = np.ascontiguousarray(args.twine_spread, np.float32)
+        j.ntaps = len(taps)
+        j.taps = taps.ctypes.data_as(C.POINTER(C.c_float))
+    j.row_begin = row_begin
+    j.row_end = args.height if row_end is None else row_end
+    j.stage = stage
+    j.nthreads = nthreads
+    och = 3 if stage else osrc.nch
+    out = np.zeros((j.row_end - j.row_begin, args.width, och), np.float32)
+    rc = euo.lib().euo_render(C.byref(j), C.byref(osrc.s), 1, euo.ptr(out), args.width * och)
+    assert rc == 0, rc
+    return out
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def ulp_diff(a, b):
+    """distance in float32 ULPs (monotone integer mapping of the bit patterns)"""
+    def key(v):
+        u = bits(v).astype(np.int64)
+        return np.where(u & 0x80000000, 0x80000000 - u, u)
+    return np.abs(key(a) - key(b))

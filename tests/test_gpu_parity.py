@@ -1,0 +1,183 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the
+CPU oracle on identical inputs. BIT-EXACT (float32 compared as uint32) at every
+stage: rays, source coordinates, pixels, and the device-built coefficients."""
+import math
+
+import numpy as np
+import pytest
+
+import envutil_amd as ea
+import euo
+import jobs
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_bits(a, b, what=""):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    bad = np.argwhere(jobs.bits(a) != jobs.bits(b))
+    if bad.size:
+        i = tuple(bad[0])
+        ul = jobs.ulp_diff(a, b).max()
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} floats differ (max {ul} ULP); "
+                             f"first at {i}: gpu {a[i]!r} oracle {b[i]!r}")
+
+
+SRC_W, SRC_H = 256, 128
+
+
+@pytest.fixture(scope="module")
+def latlon():
+    return {n: jobs.synth_image(SRC_W, SRC_H, n) for n in (1, 3, 4)}
+
+
+def make_pair(prj, w, h, hfov, img, degree, pdeg=None, **kw):
+    o = jobs.OracleSource(prj, w, h, hfov, img, degree, pdeg, **kw)
+    fct = ea.facet_spec(prj, w, h, hfov, nchannels=img.shape[2],
+                        yaw=kw.get("yaw", 0.0), pitch=kw.get("pitch", 0.0),
+                        roll=kw.get("roll", 0.0), brighten=kw.get("brighten", 1.0))
+    # the GPU gets the oracle's coefficients: stage-wise parity of the render
+    # path alone ("given identical coefficients")
+    g = ea.Source.adopt(fct, o.container, degree, o.bc[0], o.bc[1])
+    return o, g
+
+
+TARGETS = [
+    (ea.CUBEMAP, 40, 240, 90.0),
+    (ea.SPHERICAL, 200, 100, 360.0),
+    (ea.RECTILINEAR, 129, 97, 90.0),
+    (ea.CYLINDRICAL, 150, 70, 220.0),
+    (ea.BIATAN6, 24, 144, 90.0),
+    (ea.SPHERICAL, 1100, 12, 360.0),      # segments of 512 + leftover lanes
+]
+
+
+@pytest.mark.parametrize("tprj,tw,th,thfov", TARGETS)
+@pytest.mark.parametrize("ypr", [(0, 0, 0), (30, 15, 7.5)])
+def test_rays_bit_exact(latlon, tprj, tw, th, thfov, ypr):
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 1)
+    for twine in (0, 2):
+        a = ea.arguments(tprj, tw, th, thfov, yaw=ypr[0], pitch=ypr[1], roll=ypr[2],
+                         spline_degree=1, twine=twine)
+        assert_bits(ea.render(a, g, stage=1), jobs.oracle_render(a, o, stage=1), "rays")
+
+
+@pytest.mark.parametrize("tprj,tw,th,thfov", TARGETS[:4])
+def test_source_coordinates_bit_exact(latlon, tprj, tw, th, thfov):
+    a = ea.arguments(tprj, tw, th, thfov, yaw=-40, pitch=20, roll=-5, spline_degree=1)
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 1)
+    assert_bits(ea.render(a, g, stage=2), jobs.oracle_render(a, o, stage=2), "lat/lon coordinate")
+    faces = jobs.synth_cubefaces(64, 3)
+    o, g = make_pair(euo.CUBEMAP, 64, 384, 90.0, faces, 1)
+    assert_bits(ea.render(a, g, stage=2), jobs.oracle_render(a, o, stage=2), "cubemap pickup")
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("nch", [1, 3, 4])
+def test_pixels_bit_exact_latlon_source(latlon, degree, nch):
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[nch], degree)
+    for tprj, tw, th, thfov in TARGETS[:3]:
+        a = ea.arguments(tprj, tw, th, thfov, yaw=12, pitch=-33, roll=4, spline_degree=degree)
+        assert_bits(ea.render(a, g), jobs.oracle_render(a, o), f"pixels deg {degree} nch {nch} prj {tprj}")
+
+
+@pytest.mark.parametrize("sprj,sw,sh,shfov", [
+    (euo.RECTILINEAR, 200, 150, 80.0),      # misses: outside the window -> 0
+    (euo.CYLINDRICAL, 256, 100, 360.0),
+    (euo.SPHERICAL, 200, 80, 220.0),        # partial sphere: REFLECT, ordinary prefilter
+    (euo.STEREOGRAPHIC, 160, 160, 150.0),
+])
+def test_pixels_bit_exact_other_mounts(sprj, sw, sh, shfov):
+    img = jobs.synth_image(sw, sh, 3, seed=99)
+    o, g = make_pair(sprj, sw, sh, shfov, img, 3, yaw=10, pitch=5, roll=-3, brighten=1.25)
+    for tprj, tw, th, thfov in [(ea.SPHERICAL, 160, 80, 360.0), (ea.RECTILINEAR, 100, 80, 70.0)]:
+        a = ea.arguments(tprj, tw, th, thfov, yaw=5, pitch=2, roll=1, spline_degree=3)
+        got, ref = ea.render(a, g), jobs.oracle_render(a, o)
+        assert_bits(got, ref, f"mount {sprj}")
+    assert (ref == 0).any() or sprj == euo.CYLINDRICAL   # the miss path was exercised
+
+
+@pytest.mark.parametrize("sprj", [euo.CUBEMAP, euo.BIATAN6])
+@pytest.mark.parametrize("degree", [1, 3])
+def test_pixels_bit_exact_cubemap_source(sprj, degree):
+    faces = jobs.synth_cubefaces(64, 3)
+    o, g = make_pair(sprj, 64, 384, 90.0, faces, degree)
+    for tprj, tw, th, thfov in [(ea.SPHERICAL, 256, 128, 360.0), (ea.CUBEMAP, 48, 288, 90.0)]:
+        a = ea.arguments(tprj, tw, th, thfov, yaw=45, pitch=35.26, roll=0, spline_degree=degree)
+        assert_bits(ea.render(a, g), jobs.oracle_render(a, o), "cubemap source")
+
+
+@pytest.mark.parametrize("twine", [2, 3])
+@pytest.mark.parametrize("tprj,tw,th,thfov", TARGETS[:5])
+def test_twining_bit_exact(latlon, twine, tprj, tw, th, thfov):
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 1)
+    a = ea.arguments(tprj, tw, th, thfov, yaw=30, pitch=15, roll=7.5, spline_degree=1, twine=twine)
+    assert_bits(ea.render(a, g), jobs.oracle_render(a, o), "twining")
+
+
+def test_twining_gaussian_taps_and_rgba(latlon):
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[4], 3, brighten=0.8)
+    a = ea.arguments(ea.SPHERICAL, 96, 48, 360.0, yaw=3, spline_degree=3, twine=5,
+                     twine_width=1.3, twine_sigma=1.2, twine_threshold=0.01)
+    assert len(a.twine_spread) < 25
+    assert_bits(ea.render(a, g), jobs.oracle_render(a, o), "gaussian twining")
+
+
+def test_row_tiles_equal_the_whole(latlon):
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 3)
+    a = ea.arguments(ea.CUBEMAP, 40, 240, 90.0, spline_degree=3)
+    whole = ea.render(a, g)
+    for r0, r1 in [(0, 30), (30, 61), (61, 240), (100, 100)]:
+        assert_bits(ea.render(a, g, row_begin=r0, row_end=r1), whole[r0:r1], "row tile")
+    assert_bits(whole, jobs.oracle_render(a, o), "whole")
+
+
+# ---- device-side set-up: coefficients built in HBM ------------------------
+
+@pytest.mark.parametrize("degree,pdeg", [(0, 0), (1, 1), (2, 2), (3, 3), (5, 5), (1, 3), (4, 3)])
+def test_device_spherical_prefilter_bit_exact(latlon, degree, pdeg):
+    for nch in (3, 4):
+        fct = ea.facet_spec(ea.SPHERICAL, SRC_W, SRC_H, 360.0, nchannels=nch)
+        g = ea.Source.load(fct, latlon[nch], degree, pdeg)
+        o = jobs.OracleSource(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[nch], degree, pdeg)
+        assert_bits(g.download(), o.container, f"spherical coefficients deg {degree}/{pdeg}")
+
+
+@pytest.mark.parametrize("sprj,sw,sh,shfov", [(euo.RECTILINEAR, 200, 150, 80.0),
+                                             (euo.CYLINDRICAL, 256, 100, 360.0),
+                                             (euo.SPHERICAL, 30, 9, 100.0)])
+@pytest.mark.parametrize("degree", [1, 2, 3, 7])
+def test_device_ordinary_prefilter_bit_exact(sprj, sw, sh, shfov, degree):
+    img = jobs.synth_image(sw, sh, 3, seed=5)
+    g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov), img, degree)
+    o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree)
+    assert_bits(g.download(), o.container, "ordinary coefficients")
+
+
+@pytest.mark.parametrize("face,degree", [(64, 1), (64, 3), (100, 3), (128, 2)])
+def test_device_cubemap_ir_bit_exact(face, degree):
+    faces = jobs.synth_cubefaces(face, 3)
+    g = ea.Source.load(ea.facet_spec(ea.CUBEMAP, face, 6 * face, 90.0), faces, degree)
+    o = jobs.OracleSource(euo.CUBEMAP, face, 6 * face, 90.0, faces, degree)
+    assert_bits(g.download(), o.container, "cubemap IR")
+
+
+def test_end_to_end_load_and_render_matches_oracle(latlon):
+    """config-2/headline shape at test size: everything on the device"""
+    fct = ea.facet_spec(ea.SPHERICAL, SRC_W, SRC_H, 360.0)
+    g = ea.Source.load(fct, latlon[3], 3)
+    o = jobs.OracleSource(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 3)
+    a = ea.arguments(ea.CUBEMAP, 64, 384, 90.0, spline_degree=3)
+    dp = ea.get_dispatch().bind(a, g)
+    assert dp.payload(3, 3, ea.CUBEMAP) == 0
+    assert_bits(dp.result, jobs.oracle_render(a, o), "payload")
+
+
+def test_identity_reprojection_property(latlon):
+    """size-independent property: a full-sphere image reprojected onto its own
+    grid with a prefiltered cubic spline reproduces itself to the prefilter
+    tolerance (1e-4, environment.h:381-385)"""
+    fct = ea.facet_spec(ea.SPHERICAL, SRC_W, SRC_H, 360.0)
+    g = ea.Source.load(fct, latlon[3], 3)
+    a = ea.arguments(ea.SPHERICAL, SRC_W, SRC_H, 360.0, spline_degree=3)
+    assert np.abs(ea.render(a, g) - latlon[3]).max() < 2e-4
