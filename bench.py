@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py - whole-job throughput of the MI355X-native reprojection path.
+
+One "step" = one pass of the hot path over one frame: every output pixel of the
+headline job (16384x8192 lat/lon -> 6x4096 cubemap, b-spline degree 3 with
+prefilter, RGB float32) is produced once, with the prefiltered source
+coefficients already resident in HBM. With N GPUs the output rows are tiled
+across the ranks (source replicated by one RCCL broadcast at set-up, no
+collective inside a step); value = pixels all ranks produced / max-over-ranks
+time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task
+description), including
+  roofline     - algorithmic bytes per launch / mean kernel time measured with
+                 HIP events on the kernel's own stream, against 8 TB/s HBM
+  cpu_baseline - the CPU oracle (a port of the reference path, NOT envutil's
+                 SIMD binary) timed on this box's host cores on a band of rows
+                 of the same frame.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (source (prj, w, h, hfov), target (prj, w, h, hfov), nch, degree, twine, ypr)
+    "headline": (("spherical", 16384, 8192, 360.0), ("cubemap", 4096, 24576, 90.0), 3, 3, 0, (0, 0, 0)),
+    "config2": (("spherical", 8192, 4096, 360.0), ("cubemap", 2048, 12288, 90.0), 3, 1, 0, (0, 0, 0)),
+    "config3": (("cubemap", 2048, 12288, 90.0), ("spherical", 16384, 8192, 360.0), 3, 3, 0, (0, 0, 0)),
+    "config4": (("spherical", 32768, 16384, 360.0), ("spherical", 32768, 16384, 360.0), 3, 1, 3, (30, 15, 7.5)),
+    "small": (("spherical", 2048, 1024, 360.0), ("cubemap", 512, 3072, 90.0), 3, 3, 0, (0, 0, 0)),
+}
+WORKLOAD_TEXT = {
+    "headline": "16384x8192 lat/lon -> 6x4096 cubemap, b-spline degree 3 + prefilter, RGB f32",
+    "config2": "8192x4096 lat/lon -> 6x2048 cubemap, bilinear, RGB f32",
+    "config3": "6x2048 cubemap -> 16384x8192 spherical, b-spline degree 3 + prefilter, RGB f32",
+    "config4": "32768x16384 lat/lon -> 32768x16384 spherical, ypr 30/15/7.5, 3x3 twining, bilinear, RGB f32",
+    "small": "2048x1024 lat/lon -> 6x512 cubemap, b-spline degree 3 (smoke size)",
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+class _DevBuf:
+    """exposes a raw device pointer to torch through __cuda_array_interface__"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4",
+                                         "data": (ptr, False), "version": 2}
+
+
+def synth_on_device(torch, dev, w, h, nch):
+    """SURVEY.md 8(d) synthetic field, generated on the GPU (f32)"""
+    x = torch.arange(w, device=dev, dtype=torch.float32)[None, :]
+    y = torch.arange(h, device=dev, dtype=torch.float32)[:, None]
+    img = torch.empty((h, w, nch), device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev)
+    for c in range(nch):
+        smooth = 0.5 + 0.25 * torch.sin(2 * math.pi * (3 + c) * x / w) * torch.cos(2 * math.pi * (2 + c) * y / h)
+        g.manual_seed(12345 + c)
+        noise = torch.rand((h, w), device=dev, generator=g)
+        img[:, :, c] = smooth + 0.05 * noise - 0.025
+    return img
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import envutil_amd as ea
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available() or ea.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    ea.lib().eu_hip_init(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    (sname, sw, sh, shfov), (tname, tw, th, thfov), nch, degree, twine, ypr = WORKLOADS[a.workload]
+    from envutil_amd.api import PROJECTION_NAMES
+    sprj, tprj = PROJECTION_NAMES.index(sname), PROJECTION_NAMES.index(tname)
+
+    # ---- set-up (untimed): source coefficients into HBM on every rank ------
+    fct = ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch)
+    t_setup = time.time()
+    if rank == 0:
+        img = synth_on_device(torch, dev, sw, sh, nch)
+        host = img.cpu().numpy()
+        del img
+        torch.cuda.empty_cache()
+        src = ea.Source.load(fct, host, degree)          # H2D + device prefilter/brace
+        del host
+    else:
+        src = ea.Source.alloc(fct, degree)
+    if world > 1:
+        ptr, n = src.device_ptr()
+        buf = torch.as_tensor(_DevBuf(ptr, n), device=dev)
+        dist.broadcast(buf, 0)                           # RCCL over xGMI, once per source
+        torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    args = ea.arguments(tprj, tw, th, thfov, yaw=ypr[0], pitch=ypr[1], roll=ypr[2],
+                        spline_degree=degree, twine=twine)
+    # row tile of this rank
+    r0 = (th * rank) // world
+    r1 = (th * (rank + 1)) // world
+    out = torch.empty(((r1 - r0), tw, nch), device=dev, dtype=torch.float32)
+    srcs = (C.c_void_p * 1)(src.handle)
+    tgt = args.target(nch, r0, r1, 0)
+
+    def step():
+        rc = ea.lib().eu_hip_render(C.byref(tgt), srcs, 1, C.c_void_p(out.data_ptr()),
+                                    tw * nch * 4, 1, None)
+        if rc:
+            raise SystemExit("render failed: " + ea.lib().eu_hip_last_error().decode())
+
+    def sync_all():
+        ea.lib().eu_hip_sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ea.lib().eu_hip_sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- kernel-only time with HIP events on the kernel's stream ------------
+    kernel_ms = ea.render_timed(args, src, out.data_ptr(), max(a.steps, 5), nch, r0, r1)
+
+    npix_total = tw * th
+    npix_rank = tw * (r1 - r0)
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = npix_total * a.steps / elapsed / 1e6
+
+    # algorithmic bytes of one launch on this rank: every core coefficient the
+    # frame needs read once (the whole source: each rank's tile of a cubemap
+    # spans all longitudes) + every output pixel of the tile written once
+    # (B_alg = 4*NCH*(N_src + N_out))
+    if sprj in (ea.CUBEMAP, ea.BIATAN6):
+        sec = ea.cubemap_metrics(sw)["section_px"]
+        n_src = sec * 6 * sec
+    else:
+        n_src = sw * sh
+    src_share = n_src if world == 1 else n_src / world
+    alg_bytes = 4.0 * nch * (src_share + npix_rank)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf) and world == 1:
+        try:
+            rec = json.load(open(tf))
+            if rec.get("workload") == a.workload:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "Mpix/s reprojected (16K lat/lon->cubemap, b-spline-3)",
+        "value": round(value, 1),
+        "unit": "Mpix/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": WORKLOAD_TEXT[a.workload], "name": a.workload,
+                   "channels": nch, "spline_degree": degree, "twine": twine,
+                   "rows_per_gpu": r1 - r0, "tiling": f"rows/{world}",
+                   "setup_s": round(t_setup, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic,
+                     "kernel": "eu_render_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes": alg_bytes},
+    }
+
+    # ---- CPU baseline: the oracle (a port) on a band of rows, rank 0, N=1 ----
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import euo
+        import jobs
+        cont = src.download()
+        g, _ = src.info()
+        osrc = jobs.OracleSource.__new__(jobs.OracleSource)
+        s = euo.Source()
+        s.projection = sprj
+        s.hfov = math.radians(shfov)
+        s.width, s.height = sw, sh
+        s.window_width, s.window_height = sw, sh
+        s.brighten = 1.0
+        sp = euo.Spline()
+        sp.data = cont.ctypes.data_as(C.POINTER(C.c_float))
+        sp.shape[0], sp.shape[1] = g.shape[0], g.shape[1]
+        sp.stride[0], sp.stride[1] = 1, g.shape[0]
+        sp.left[0], sp.left[1] = g.left[0], g.left[1]
+        sp.right[0], sp.right[1] = g.right[0], g.right[1]
+        sp.core[0], sp.core[1] = g.core[0], g.core[1]
+        if sprj in (ea.CUBEMAP, ea.BIATAN6):
+            sp.bc[0] = sp.bc[1] = euo.REFLECT
+            m = ea.cubemap_metrics(sw)
+            s.refc_md = np.float32(m["refc_md"])
+            s.model_to_px = np.float32(m["model_to_px"])
+            s.section_px = m["section_px"]
+        else:
+            sp.bc[0], sp.bc[1] = jobs.source_bcs(sprj, math.radians(shfov))
+        sp.degree = degree
+        sp.nch = nch
+        s.spl = sp
+        osrc.s, osrc.nch, osrc.degree, osrc.container = s, nch, degree, cont
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        # probe, then size the band for about --cpu-seconds of work
+        probe_rows = max(1, min(th // 6, (4 * cores)))
+        mid = th // 12          # inside the first cube face / upper part of the frame
+        t = time.perf_counter()
+        jobs.oracle_render(args, osrc, 0, mid, mid + probe_rows, nthreads=cores)
+        dt = time.perf_counter() - t
+        rows = int(max(probe_rows, min(th, probe_rows * a.cpu_seconds / max(dt, 1e-3))))
+        rows = min(rows, th)
+        # spread the band over the frame: take it from the middle
+        b0 = max(0, (th - rows) // 2)
+        t = time.perf_counter()
+        ref = jobs.oracle_render(args, osrc, 0, b0, b0 + rows, nthreads=cores)
+        dt = time.perf_counter() - t
+        # the same rows from the GPU: the baseline run doubles as a full-size
+        # parity spot check
+        chk = ea.render(args, src, nch, b0, b0 + rows)
+        same = bool((chk.view(np.uint32) == ref.view(np.uint32)).all())
+        result["cpu_baseline"] = {
+            "value": round(rows * tw / dt / 1e6, 2), "unit": "Mpix/s", "cores": cores,
+            "kind": "port",
+            "sample": f"rows {b0}..{b0 + rows} of the same frame ({rows * tw / 1e6:.1f} Mpix, {dt:.1f} s), "
+                      "oracle/eu_oracle.c with OpenMP; not envutil's SIMD binary",
+            "gpu_rows_bit_identical": same,
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

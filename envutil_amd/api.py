@@ -83,6 +83,8 @@ def lib():
     L.eu_hip_container_geometry.argtypes = [i32, i32, i32, C.c_int64, C.c_int64, vp]
     L.eu_hip_source_load.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.eu_hip_source_adopt.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.eu_hip_source_alloc.argtypes = [vp, i32, i32, i32, vp]
+    L.eu_hip_source_device_ptr.argtypes = [vp, vp, vp]
     L.eu_hip_source_download.argtypes = [vp, vp, C.c_size_t]
     L.eu_hip_source_info.argtypes = [vp, vp, vp]
     L.eu_hip_source_release.argtypes = [vp]
@@ -202,6 +204,21 @@ class Source:
         _check(lib().eu_hip_source_adopt(C.byref(cf), _ptr(container), spline_degree, bc0,
                                          bc1, support_min, tile_size, C.byref(h)))
         return cls(h, fct)
+
+    @classmethod
+    def alloc(cls, fct, spline_degree, support_min=8, tile_size=64):
+        """an unfilled container in HBM (to be filled by a broadcast)"""
+        cf = fct.c_struct()
+        h = C.c_void_p()
+        _check(lib().eu_hip_source_alloc(C.byref(cf), spline_degree, support_min, tile_size,
+                                         C.byref(h)))
+        return cls(h, fct)
+
+    def device_ptr(self):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        _check(lib().eu_hip_source_device_ptr(self.handle, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def info(self):
         g = Container()

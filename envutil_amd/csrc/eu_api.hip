@@ -44,6 +44,11 @@ struct context {
   float *col = nullptr, *row = nullptr, *taps = nullptr;
   size_t col_cap = 0, row_cap = 0, taps_cap = 0;
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
+  // the tables of the last target stay valid while (target geometry,
+  // orientation, taps) repeat: streaming / tethered jobs re-render the same
+  // target many times (envutil_main.cc:1948-1982)
+  std::vector<unsigned char> plan_key;
+  int plan_form = 0, plan_norm = 0;
 } g;
 
 #define HIPCHK(call)                                                          \
@@ -206,28 +211,45 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   eu::mat3 r_cam = eu::make_r3(t->roll, t->pitch, t->yaw, false);
   eu::mat3 r_fct = eu::make_r3(s->fct.roll, s->fct.pitch, s->fct.yaw, true);
   eu::mat3 basis = eu::rotate(r_cam, r_fct);
-  eu::stepper_tables tb;
-  if (!eu::build_stepper_tables(*t, basis, twine, twine, tb))
-    return fail(EU_ERR_UNSUPPORTED, "fisheye/stereographic target steppers not built yet");
-  int rc;
-  if ((rc = grow(&g.col, &g.col_cap, tb.col.size()))) return rc;
-  if ((rc = grow(&g.row, &g.row_cap, tb.row.size()))) return rc;
-  HIPCHK(hipMemcpyAsync(g.col, tb.col.data(), tb.col.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
-  HIPCHK(hipMemcpyAsync(g.row, tb.row.data(), tb.row.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
-  std::vector<float> taps;
-  if (twine) {
-    // twine_t ctor: x, y pre-multiplied by the bias 4.0 (twining.h:106-121)
-    taps.assign(t->taps, t->taps + 3 * (size_t)t->ntaps);
-    for (int k = 0; k < t->ntaps; k++) { taps[3 * k] *= 4.0f; taps[3 * k + 1] *= 4.0f; }
-    if ((rc = grow(&g.taps, &g.taps_cap, taps.size()))) return rc;
-    HIPCHK(hipMemcpyAsync(g.taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+  // plan key: everything the tables depend on
+  std::vector<unsigned char> key(sizeof(eu_target) + 3 * sizeof(double) + 3 * sizeof(float) * (size_t)t->ntaps);
+  {
+    eu_target tk = *t;
+    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0;
+    unsigned char *q = key.data();
+    memcpy(q, &tk, sizeof tk); q += sizeof tk;
+    double fo[3] = { s->fct.yaw, s->fct.pitch, s->fct.roll };
+    memcpy(q, fo, sizeof fo); q += sizeof fo;
+    if (twine) memcpy(q, t->taps, 3 * sizeof(float) * (size_t)t->ntaps);
   }
-  // the host vectors die at return: the copies must have left them
-  HIPCHK(hipStreamSynchronize(g.stream));
+  int rc;
+  int form = g.plan_form, norm_mode = g.plan_norm;
+  if (key != g.plan_key) {
+    eu::stepper_tables tb;
+    if (!eu::build_stepper_tables(*t, basis, twine, twine, tb))
+      return fail(EU_ERR_UNSUPPORTED, "fisheye/stereographic target steppers not built yet");
+    if ((rc = grow(&g.col, &g.col_cap, tb.col.size()))) return rc;
+    if ((rc = grow(&g.row, &g.row_cap, tb.row.size()))) return rc;
+    HIPCHK(hipMemcpyAsync(g.col, tb.col.data(), tb.col.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.row, tb.row.data(), tb.row.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    std::vector<float> taps;
+    if (twine) {
+      // twine_t ctor: x, y pre-multiplied by the bias 4.0 (twining.h:106-121)
+      taps.assign(t->taps, t->taps + 3 * (size_t)t->ntaps);
+      for (int k = 0; k < t->ntaps; k++) { taps[3 * k] *= 4.0f; taps[3 * k + 1] *= 4.0f; }
+      if ((rc = grow(&g.taps, &g.taps_cap, taps.size()))) return rc;
+      HIPCHK(hipMemcpyAsync(g.taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    }
+    // the host vectors die at the end of this block: the copies must have left them
+    HIPCHK(hipStreamSynchronize(g.stream));
+    form = g.plan_form = tb.form;
+    norm_mode = g.plan_norm = tb.norm_mode;
+    g.plan_key.swap(key);
+  }
   memset(p, 0, sizeof *p);
   p->width = t->width; p->height = t->height;
   p->row_begin = t->row_begin; p->row_end = t->row_end;
-  p->form = tb.form; p->norm_mode = tb.norm_mode;
+  p->form = form; p->norm_mode = norm_mode;
   p->twine = twine; p->ntaps = t->ntaps; p->stage = t->stage; p->nch = s->nch;
   p->col = g.col; p->row = g.row; p->taps = g.taps;
   p->out = out_dev;
@@ -370,6 +392,26 @@ int eu_hip_source_load(const eu_facet *fct, const float *pixels, int spline_degr
     return fail(rc, "device set-up stage failed");
   }
   *out = s;
+  return EU_OK;
+}
+
+int eu_hip_source_alloc(const eu_facet *fct, int spline_degree, int support_min, int tile_size,
+                        eu_source **out)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if ((rc = check_facet(fct))) return rc;
+  if (!out) return fail(EU_ERR_ARGUMENT, "null argument");
+  int bc0, bc1;
+  source_bcs(fct, &bc0, &bc1);
+  return new_source(fct, spline_degree, bc0, bc1, support_min, tile_size, out);
+}
+
+int eu_hip_source_device_ptr(const eu_source *src, void **dev_ptr, size_t *nfloats)
+{
+  if (!src) return fail(EU_ERR_HANDLE, "null source");
+  if (dev_ptr) *dev_ptr = src->dev;
+  if (nfloats) *nfloats = src->nfloats;
   return EU_OK;
 }
 

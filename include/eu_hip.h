@@ -131,6 +131,14 @@ int  eu_hip_source_load(const eu_facet *fct, const float *pixels,
 int  eu_hip_source_adopt(const eu_facet *fct, const float *container,
                          int spline_degree, int bc0, int bc1,
                          int support_min, int tile_size, eu_source **out);
+/* Allocate the container for a facet without filling it, and expose its device
+ * address: the multi-GPU host broadcasts rank 0's prefiltered coefficients
+ * straight into it over RCCL/xGMI - one broadcast per source,
+ * after which the source stays resident like any other. */
+int  eu_hip_source_alloc(const eu_facet *fct, int spline_degree,
+                         int support_min, int tile_size, eu_source **out);
+int  eu_hip_source_device_ptr(const eu_source *src, void **dev_ptr,
+                              size_t *nfloats);
 /* copy the device-resident container back (tests, checkpointing) */
 int  eu_hip_source_download(const eu_source *src, float *container,
                             size_t nfloats);

@@ -4,4 +4,4 @@ set -e
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 make -s -C oracle _build/libeu_oracle.so
-python -m pytest tests -m gpu -x -q 2>&1 | tee gpurun_out/pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | tee gpurun_out/pytest_gpu.log

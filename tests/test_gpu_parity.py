@@ -94,7 +94,9 @@ def test_pixels_bit_exact_other_mounts(sprj, sw, sh, shfov):
         a = ea.arguments(tprj, tw, th, thfov, yaw=5, pitch=2, roll=1, spline_degree=3)
         got, ref = ea.render(a, g), jobs.oracle_render(a, o)
         assert_bits(got, ref, f"mount {sprj}")
-    assert (ref == 0).any() or sprj == euo.CYLINDRICAL   # the miss path was exercised
+        if tprj == ea.SPHERICAL and sprj != euo.CYLINDRICAL:
+            # the source does not cover the sphere: the miss path was exercised
+            assert (ref == 0).all(axis=2).any() and (ref != 0).any()
 
 
 @pytest.mark.parametrize("sprj", [euo.CUBEMAP, euo.BIATAN6])
@@ -118,7 +120,7 @@ def test_twining_bit_exact(latlon, twine, tprj, tw, th, thfov):
 def test_twining_gaussian_taps_and_rgba(latlon):
     o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[4], 3, brighten=0.8)
     a = ea.arguments(ea.SPHERICAL, 96, 48, 360.0, yaw=3, spline_degree=3, twine=5,
-                     twine_width=1.3, twine_sigma=1.2, twine_threshold=0.01)
+                     twine_width=1.3, twine_sigma=1.2, twine_threshold=0.03)
     assert len(a.twine_spread) < 25
     assert_bits(ea.render(a, g), jobs.oracle_render(a, o), "gaussian twining")
 
