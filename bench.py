@@ -37,6 +37,9 @@ WORKLOADS = {
     "config3": (("cubemap", 2048, 12288, 90.0), ("spherical", 16384, 8192, 360.0), 3, 3, 0, (0, 0, 0)),
     "config4": (("spherical", 32768, 16384, 360.0), ("spherical", 32768, 16384, 360.0), 3, 1, 3, (30, 15, 7.5)),
     "small": (("spherical", 2048, 1024, 360.0), ("cubemap", 512, 3072, 90.0), 3, 3, 0, (0, 0, 0)),
+    # diagnostic shapes (not bench lines): headline-sized target, cache-resident source
+    "probe_smallsrc": (("spherical", 2048, 1024, 360.0), ("cubemap", 4096, 24576, 90.0), 3, 3, 0, (0, 0, 0)),
+    "probe_bilinear": (("spherical", 16384, 8192, 360.0), ("cubemap", 4096, 24576, 90.0), 3, 1, 0, (0, 0, 0)),
 }
 WORKLOAD_TEXT = {
     "headline": "16384x8192 lat/lon -> 6x4096 cubemap, b-spline degree 3 + prefilter, RGB f32",
@@ -44,6 +47,8 @@ WORKLOAD_TEXT = {
     "config3": "6x2048 cubemap -> 16384x8192 spherical, b-spline degree 3 + prefilter, RGB f32",
     "config4": "32768x16384 lat/lon -> 32768x16384 spherical, ypr 30/15/7.5, 3x3 twining, bilinear, RGB f32",
     "small": "2048x1024 lat/lon -> 6x512 cubemap, b-spline degree 3 (smoke size)",
+    "probe_smallsrc": "DIAGNOSTIC 2048x1024 lat/lon -> 6x4096 cubemap, degree 3",
+    "probe_bilinear": "DIAGNOSTIC 16384x8192 lat/lon -> 6x4096 cubemap, bilinear",
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -78,6 +83,8 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--probe-stages", action="store_true",
+                    help="diagnostic: also time the kernel stopped after the ray / coordinate stage")
     a = ap.parse_args()
 
     import numpy as np
@@ -164,6 +171,15 @@ def main():
     # ---- kernel-only time with HIP events on the kernel's stream ------------
     kernel_ms = ea.render_timed(args, src, out.data_ptr(), max(a.steps, 5), nch, r0, r1)
 
+    probe = None
+    if a.probe_stages:
+        probe = {}
+        for st in (1, 2):
+            tgs = args.target(nch, r0, r1, st)
+            ms = C.c_float()
+            ea.lib().eu_hip_render_timed(C.byref(tgs), srcs, 1, C.c_void_p(out.data_ptr()),
+                                         tw * 3 * 4, 5, C.byref(ms))
+            probe[f"stage{st}_ms"] = round(ms.value, 4)
     npix_total = tw * th
     npix_rank = tw * (r1 - r0)
     ms_per_step = 1e3 * elapsed / a.steps
@@ -278,6 +294,8 @@ def main():
                       "oracle/eu_oracle.c with OpenMP; not envutil's SIMD binary",
             "gpu_rows_bit_identical": same,
         }
+    if probe:
+        result["probe"] = probe
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -14,6 +14,7 @@
 #include "eu_setup_math.h"
 
 extern "C" int eu_launch_render(const eu_render_params *p, void *stream);
+extern "C" int eu_launch_diag(const eu_render_params *p, unsigned long long *stamps_dev, void *stream);
 extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int nch,
                                    int bc0, int bc1, int prefilter_degree, int spherical,
                                    void *stream);
@@ -255,6 +256,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   p->out = out_dev;
   p->out_stride = (long long)(row_stride_bytes / sizeof(float));
   p->src = s->sd;
+  { const char *e = getenv("EU_HIP_DIRECT"); p->direct = (e && e[0] == '1') ? 1 : 0; }
   return EU_OK;
 }
 
@@ -494,6 +496,28 @@ int eu_hip_render_timed(const eu_target *trg, eu_source *const *srcs, int nsrc, 
   *mean_ms = ms / iters;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  return EU_OK;
+}
+
+// DIAGNOSTIC (not declared in eu_hip.h): phase stamps of the headline path,
+// 8 x uint64 per wave: t0..t5, XCC id, tile index
+int eu_hip_diag_stamps(const eu_target *trg, eu_source *const *srcs, int nsrc, float *out_dev,
+                       size_t out_row_stride_bytes, unsigned long long *host_stamps,
+                       size_t nwaves)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  eu_render_params p;
+  if ((rc = build_params(trg, srcs, nsrc, out_dev, out_row_stride_bytes, &p))) return rc;
+  if (p.nch != 3 || p.src.degree != 3 || p.twine) return fail(EU_ERR_ARGUMENT, "diag: NCH 3, degree 3, no twining");
+  unsigned long long *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, nwaves * 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(d, 0, nwaves * 8 * sizeof(unsigned long long), g.stream));
+  for (int i = 0; i < 3; i++)
+    if (eu_launch_diag(&p, d, g.stream)) return fail(EU_ERR_NO_DEVICE, "diag launch failed");
+  HIPCHK(hipStreamSynchronize(g.stream));
+  HIPCHK(hipMemcpy(host_stamps, d, nwaves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
   return EU_OK;
 }
 

@@ -47,6 +47,7 @@ struct eu_render_params {
   float *out;
   long long out_stride;      // floats per output row
   int tiles_x, tiles_y;      // grid of 64x4 tiles
+  int direct;                // 1: never stage through LDS (A/B switch, EU_HIP_DIRECT=1)
   eu_src_dev src;
 };
 

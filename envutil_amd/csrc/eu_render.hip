@@ -23,356 +23,11 @@
 // correctly rounded defaults). See DESIGN.md "Numerics".
 
 #include <hip/hip_runtime.h>
+#include <climits>
 #include "eu_device.h"
 #include "eu_math.h"
 
-#define EU_TILE_W 64
-#define EU_TILE_H 4
-
-// ---------------------------------------------------------------------------
-// gates: zimt/map.h:184-440
-// ---------------------------------------------------------------------------
-
-__device__ __forceinline__ float eu_vfmod(float lhs, float rhs)
-{
-  float help = lhs / rhs;
-  help = truncf(help);
-  help = help * rhs;
-  lhs = lhs - help;
-  if (fabsf(lhs) >= fabsf(rhs)) lhs = 0.0f;
-  return lhs;
-}
-
-__device__ __forceinline__ float eu_gate(float c, int kind, float lower, float upper)
-{
-  if (kind == 2) {            // periodic_gate, map.h:423-440
-    float cc = c - lower;
-    float w = upper - lower;
-    bool below = cc < 0.0f, above = cc >= w;
-    if (below || above) {
-      float cm = eu_vfmod(cc, w);
-      if (below) cm = cm + w;
-      if (cm >= w) cm = 0.0f;
-      cc = cm;
-    }
-    return cc + lower;
-  }
-  if (kind == 1) {            // mirror_gate, map.h:341-357
-    float cc = c - lower;
-    float w = upper - lower;
-    cc = fabsf(cc);
-    if (cc >= w) {
-      float cm = eu_vfmod(cc, 2 * w);
-      cm = cm - w;
-      cm = fabsf(cm);
-      cm = w - cm;
-      cc = cm;
-    }
-    return cc + lower;
-  }
-  float r = c;                // clamp_gate, map.h:231-236
-  if (c < lower) r = lower;
-  if (c > upper) r = upper;
-  return r;
-}
-
-// ---------------------------------------------------------------------------
-// b-spline evaluation: split (basis.h:102-146), weights (basis.h:650-690),
-// offsets and weighted sum (eval.h:904-1059, :1237-1300)
-// ---------------------------------------------------------------------------
-
-template <int DEG>
-__device__ __forceinline__ void eu_weights(const float *wm, float delta, float *w)
-{
-  constexpr int order = DEG + 1;
-#pragma unroll
-  for (int c = 0; c <= DEG; c++) w[c] = wm[c * order];
-  float power = delta;
-#pragma unroll
-  for (int row = 1; row <= DEG; row++) {
-#pragma unroll
-    for (int c = 0; c <= DEG; c++) w[c] = w[c] + power * wm[c * order + row];
-    if (row < DEG) power = power * delta;
-  }
-}
-
-template <int NCH, int DEG>
-__device__ __forceinline__ void eu_bspline(const eu_src_dev &s, float cx, float cy,
-                                           float *out)
-{
-  float gx = eu_gate(cx, s.gate0, s.lower0, s.upper0);
-  float gy = eu_gate(cy, s.gate1, s.lower1, s.upper1);
-  float fx = (DEG & 1) ? floorf(gx) : roundf(gx);
-  float fy = (DEG & 1) ? floorf(gy) : roundf(gy);
-  float tx = gx - fx, ty = gy - fy;
-  long long origin = (long long)(int)fx * s.es0 + (long long)(int)fy * s.es1;
-  const float *p = s.base + origin;
-  if constexpr (DEG == 0) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) out[c] = p[c];
-  } else if constexpr (DEG == 1) {
-    // eval.h:1004-1059
-    float wl0 = 1.0f - tx, wr0 = tx, wl1 = 1.0f - ty, wr1 = ty;
-    const float *q = p + s.es1;
-    float a[NCH], b[NCH], c2[NCH], d[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) { a[c] = p[c]; b[c] = p[s.es0 + c]; c2[c] = q[c]; d[c] = q[s.es0 + c]; }
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      float sum = a[c] * wl0;
-      sum = sum + b[c] * wr0;
-      sum = sum * wl1;
-      float sub = c2[c] * wl0;
-      sub = sub + d[c] * wr0;
-      sum = sum + sub * wr1;
-      out[c] = sum;
-    }
-  } else {
-    constexpr int order = DEG + 1;
-    float wx[order], wy[order];
-    eu_weights<DEG>(s.wm, tx, wx);
-    eu_weights<DEG>(s.wm, ty, wy);
-    const float *p0 = p - (DEG / 2) * s.es1 - (DEG / 2) * s.es0;
-    float sum[NCH];
-#pragma unroll
-    for (int j = 0; j < order; j++) {
-      const float *rowp = p0 + j * s.es1;
-      float t[order][NCH];
-#pragma unroll
-      for (int i = 0; i < order; i++)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) t[i][c] = rowp[i * s.es0 + c];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        float r = t[0][c] * wx[0];
-#pragma unroll
-        for (int i = 1; i < order; i++) r = r + wx[i] * t[i][c];
-        if (j == 0) sum[c] = r * wy[0];
-        else sum[c] = sum[c] + r * wy[j];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; c++) out[c] = sum[c];
-  }
-}
-
-// runtime-degree evaluator for degrees above the specialised ones
-template <int NCH>
-__device__ void eu_bspline_generic(const eu_src_dev &s, float cx, float cy, float *out)
-{
-  const int d = s.degree, order = d + 1;
-  float gx = eu_gate(cx, s.gate0, s.lower0, s.upper0);
-  float gy = eu_gate(cy, s.gate1, s.lower1, s.upper1);
-  float fx = (d & 1) ? floorf(gx) : roundf(gx);
-  float fy = (d & 1) ? floorf(gy) : roundf(gy);
-  float tx = gx - fx, ty = gy - fy;
-  const float *p = s.base + (long long)(int)fx * s.es0 + (long long)(int)fy * s.es1;
-  float wx[EU_MAX_DEGREE + 1], wy[EU_MAX_DEGREE + 1];
-  for (int c = 0; c <= d; c++) { wx[c] = s.wm[c * order]; wy[c] = wx[c]; }
-  float px = tx, py = ty;
-  for (int row = 1; row <= d; row++) {
-    for (int c = 0; c <= d; c++) {
-      wx[c] = wx[c] + px * s.wm[c * order + row];
-      wy[c] = wy[c] + py * s.wm[c * order + row];
-    }
-    if (row < d) { px = px * tx; py = py * ty; }
-  }
-  const float *p0 = p - (d / 2) * s.es1 - (d / 2) * s.es0;
-  float sum[NCH];
-  for (int j = 0; j < order; j++) {
-    const float *rowp = p0 + j * s.es1;
-    for (int c = 0; c < NCH; c++) {
-      float r = rowp[c] * wx[0];
-      for (int i = 1; i < order; i++) r = r + wx[i] * rowp[i * s.es0 + c];
-      if (j == 0) sum[c] = r * wy[0];
-      else sum[c] = sum[c] + r * wy[j];
-    }
-  }
-  for (int c = 0; c < NCH; c++) out[c] = sum[c];
-}
-
-// ---------------------------------------------------------------------------
-// source lookup: ray -> source pixel coordinate
-// ---------------------------------------------------------------------------
-
-// ray_to_cubeface, geometry.h:1178-1289. The three dominance classes are
-// mutually exclusive and exhaustive; when the whole wavefront agrees (ballot)
-// only that class is evaluated - the GPU form of the reference's any_of()
-// early-outs.
-__device__ __forceinline__ void eu_cubeface(float rx, float ry, float rz,
-                                            int &face, float &in0, float &in1)
-{
-  float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
-  bool m1 = ax >= ay, m2 = ax >= az, m3 = ay >= az;
-  bool domx = m1 && m2, domz = (!m2) && (!m3);
-  unsigned long long bx = __ballot(domx), bz = __ballot(domz);
-  unsigned long long act = __ballot(1);
-  if (bx == act) {
-    face = rx < 0.0f ? 0 : 1;
-    in0 = -rz / rx;
-    in1 = ry / ax;
-  } else if (bz == act) {
-    face = rz < 0.0f ? 5 : 4;
-    in0 = rx / rz;
-    in1 = ry / az;
-  } else if ((bx | bz) == 0ull) {
-    face = ry < 0.0f ? 2 : 3;
-    in0 = -rx / ay;
-    in1 = rz / ry;
-  } else {
-    // mixed wavefront near a cube edge: select per lane
-    float num0 = domx ? -rz : (domz ? rx : -rx);
-    float den0 = domx ? rx : (domz ? rz : ay);
-    float num1 = domx ? ry : (domz ? ry : rz);
-    float den1 = domx ? ax : (domz ? az : ry);
-    in0 = num0 / den0;
-    in1 = num1 / den1;
-    face = domx ? (rx < 0.0f ? 0 : 1) : (domz ? (rz < 0.0f ? 5 : 4) : (ry < 0.0f ? 2 : 3));
-  }
-}
-
-// returns false for a miss (mount_t::get_coordinate mask, environment.h:1117-1149)
-__device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float rx,
-                                                     float ry, float rz, float &sx,
-                                                     float &sy, int &face)
-{
-  face = 0;
-  if (s.prj == EU_CUBEMAP || s.prj == EU_BIATAN6) {
-    float in0, in1;
-    eu_cubeface(rx, ry, rz, face, in0, in1);
-    if (s.prj == EU_BIATAN6) {
-      const float k = (float)(4.0 / 3.14159265358979323846);
-      in0 = k * eu_atanf(in0);
-      in1 = k * eu_atanf(in1);
-    }
-    // cubemap_view_t::get_pickup_coordinate_px, environment.h:1452-1460
-    float p0 = in0 + s.refc_md, p1 = in1 + s.refc_md;
-    p0 = p0 * s.model_to_px;
-    p1 = p1 * s.model_to_px;
-    p1 = p1 + (float)(face * s.section_px);
-    sx = p0 - .5f;
-    sy = p1 - .5f;
-    return true;
-  }
-  float c0, c1;
-  switch (s.prj) {
-    case EU_SPHERICAL: {       // ray_to_ll_t, geometry.h:278-301
-      float q = sqrtf(rx * rx + rz * rz);
-      c1 = eu_atan2f(ry, q);
-      c0 = eu_atan2f(rx, rz);
-      break;
-    }
-    case EU_CYLINDRICAL: {     // ray_to_cyl_t, geometry.h:389-410
-      float q = sqrtf(rx * rx + rz * rz);
-      c1 = ry / q;
-      c0 = eu_atan2f(rx, rz);
-      break;
-    }
-    case EU_RECTILINEAR:       // ray_to_rect_t, geometry.h:328-345
-      c0 = rx / rz;
-      c1 = ry / rz;
-      break;
-    case EU_STEREOGRAPHIC: {   // ray_to_ster_t, geometry.h:445-465
-      float rn = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
-      float r = rx * rn, d = ry * rn, f = rz * rn;
-      float factor = 2.0f / (f + 1.0f);
-      c0 = r * factor;
-      c1 = d * factor;
-      break;
-    }
-    default:
-      // fisheye sources need sinf/cosf with libm's bits: next row of the plan
-      c0 = 0.0f; c1 = 0.0f;
-      break;
-  }
-  // source_t::test_crd, environment.h:970-977 (float compares)
-  bool mask = c0 >= s.wex0 && c0 <= s.wex1 && c1 >= s.wex2 && c1 <= s.wex3;
-  if (s.prj == EU_RECTILINEAR) mask = mask && (rz > 0.0f);
-  // source_t::md_to_spline, environment.h:988-1006: the subtraction is done in
-  // double (vec<float> - double), everything after it in float
-  float i0 = (float)((double)c0 - s.tex_x0);
-  i0 = i0 / s.ext_w;
-  i0 = i0 * s.total_w;
-  i0 = i0 - .5f;
-  float i1 = (float)((double)c1 - s.tex_y0);
-  i1 = i1 / s.ext_h;
-  i1 = i1 * s.total_h;
-  i1 = i1 - .5f;
-  sx = i0 - s.win_x_off;
-  sy = i1 - s.win_y_off;
-  return mask;
-}
-
-template <int NCH, int DEG>
-__device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
-                                               float rz, float *px)
-{
-  float sx, sy;
-  int face;
-  bool hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
-  if (hit) {
-    if constexpr (DEG >= 0) eu_bspline<NCH, DEG>(s, sx, sy, px);
-    else eu_bspline_generic<NCH>(s, sx, sy, px);
-    // environment::eval, environment.h:1821-1842
-    if (s.brighten != 1.0f) {
-      constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
-#pragma unroll
-      for (int c = 0; c < ncol; c++) px[c] = px[c] * s.brighten;
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) px[c] = 0.0f;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// target side: ray of pixel (x, y) from the stepper tables
-// ---------------------------------------------------------------------------
-
-__device__ __forceinline__ void eu_ray(int form, const float *rowt, float c0, float c1,
-                                       float &rx, float &ry, float &rz)
-{
-  // rowt: A[3], B[3], C[3]
-  if (form == EU_FORM_BCA) {
-    rx = rowt[3] * c0 + rowt[6] * c1 + rowt[0];
-    ry = rowt[4] * c0 + rowt[7] * c1 + rowt[1];
-    rz = rowt[5] * c0 + rowt[8] * c1 + rowt[2];
-  } else {
-    rx = rowt[3] * c0 + rowt[0];
-    ry = rowt[4] * c0 + rowt[1];
-    rz = rowt[5] * c0 + rowt[2];
-  }
-}
-
-__device__ __forceinline__ float eu_norm3(float x, float y, float z)
-{
-  // xel.h:752-765
-  float sqn = x * x;
-  sqn = sqn + y * y;
-  sqn = sqn + z * z;
-  return sqrtf(sqn);
-}
-
-// full stepper: tables -> ray, with the normalisation flavour of the stepper
-__device__ __forceinline__ void eu_stepper(const eu_render_params &p, const float *colA,
-                                           const float *colB, const float *rowt, int x,
-                                           float &rx, float &ry, float &rz)
-{
-  eu_ray(p.form, rowt, colA[x], colB[x], rx, ry, rz);
-  if (p.norm_mode == EU_NORM_DIV) {
-    float n = eu_norm3(rx, ry, rz);
-    rx = rx / n; ry = ry / n; rz = rz / n;
-  } else if (p.norm_mode == EU_NORM_CYL) {
-    // cylindrical_stepper keeps the reciprocal length of the lane's FIRST
-    // pixel in the 512-pixel segment (stepper.h:771-775, :786)
-    int seg = (x / EU_SEGMENT) * EU_SEGMENT;
-    int x0 = seg + ((x - seg) % EU_LANES);
-    float fx, fy, fz;
-    eu_ray(p.form, rowt, colA[x0], colB[x0], fx, fy, fz);
-    float rcp = 1.0f / eu_norm3(fx, fy, fz);
-    rx = rx * rcp; ry = ry * rcp; rz = rz * rcp;
-  }
-}
+#include "eu_render_dev.h"
 
 // ---------------------------------------------------------------------------
 // the kernel
@@ -451,6 +106,131 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
 }
 
 // ---------------------------------------------------------------------------
+// the LDS-staged kernel (no twining): the workgroup's 64x4 output tile maps to
+// a compact bounding box of source texels. The box is copied into LDS once,
+// with coalesced row reads, and the (d+1)^2 taps of every pixel come from
+// there - one aligned ds_read_b128 per RGB tap instead of a 12-byte global
+// gather through L1. Tiles whose box does not fit (poles of a lat/lon source,
+// the +-180 degree seam, strong minification) take the direct path, decided
+// per workgroup.
+// ---------------------------------------------------------------------------
+
+#define EU_LDS_BYTES (20 * 1024)
+
+__device__ __forceinline__ int eu_wave_min(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int eu_wave_max(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int NCH, int DEG>
+__global__ __launch_bounds__(256) void eu_render_lds_kernel(const eu_render_params p)
+{
+  constexpr int TEX = NCH == 3 ? 4 : NCH;
+  constexpr int CAP = EU_LDS_BYTES / (TEX * 4);       // texels
+  __shared__ __attribute__((aligned(16))) float tile[CAP * TEX];
+  __shared__ int bbw[4][4];
+
+  const int nblk = p.tiles_x * p.tiles_y;
+  int b = blockIdx.x;
+  {
+    const int nx = 8;
+    int per = nblk / nx, rem = nblk % nx;
+    int xcd = b % nx, k = b / nx;
+    b = xcd * per + (xcd < rem ? xcd : rem) + k;
+  }
+  const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = tile_x * EU_TILE_W + lane;
+  const int y = p.row_begin + tile_y * EU_TILE_H + wave;
+  const bool active = y < p.row_end && x < p.width;
+
+  float rx = 0.0f, ry = 0.0f, rz = 1.0f;
+  if (active) {
+    const float *rowt = p.row + (long long)y * EU_ROW_FLOATS;
+    eu_stepper(p, p.col, p.col + p.width, rowt, x, rx, ry, rz);
+  }
+  float sx = 0.0f, sy = 0.0f;
+  int face;
+  bool hit = active && eu_source_coordinate(p.src, rx, ry, rz, sx, sy, face);
+  int ix = 0, iy = 0;
+  float tx = 0.0f, ty = 0.0f;
+  if (hit) eu_split<DEG>(p.src, sx, sy, ix, iy, tx, ty);
+
+  // bounding box of the base positions of all hitting lanes
+  int mnx = eu_wave_min(hit ? ix : INT_MAX), mny = eu_wave_min(hit ? iy : INT_MAX);
+  int mxx = eu_wave_max(hit ? ix : INT_MIN), mxy = eu_wave_max(hit ? iy : INT_MIN);
+  if (lane == 0) { bbw[wave][0] = mnx; bbw[wave][1] = mny; bbw[wave][2] = mxx; bbw[wave][3] = mxy; }
+  __syncthreads();
+  mnx = min(min(bbw[0][0], bbw[1][0]), min(bbw[2][0], bbw[3][0]));
+  mny = min(min(bbw[0][1], bbw[1][1]), min(bbw[2][1], bbw[3][1]));
+  mxx = max(max(bbw[0][2], bbw[1][2]), max(bbw[2][2], bbw[3][2]));
+  mxy = max(max(bbw[0][3], bbw[1][3]), max(bbw[2][3], bbw[3][3]));
+  mnx = __builtin_amdgcn_readfirstlane(mnx); mny = __builtin_amdgcn_readfirstlane(mny);
+  mxx = __builtin_amdgcn_readfirstlane(mxx); mxy = __builtin_amdgcn_readfirstlane(mxy);
+  const bool any = mnx != INT_MAX;
+  // window of tap (i, j): base - DEG/2 + {0..DEG}
+  const int bx0 = mnx - DEG / 2, by0 = mny - DEG / 2;
+  const long long bw = (long long)mxx - mnx + DEG + 1, bh = (long long)mxy - mny + DEG + 1;
+  const bool fits = any && bw * bh <= CAP;
+
+  float px[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) px[c] = 0.0f;
+
+  if (fits) {
+    const int ibw = (int)bw, ibh = (int)bh;
+    // stage: wave w copies rows w, w+4, ...; lanes run along x (coalesced)
+    for (int r = wave; r < ibh; r += 4) {
+      const float *g = p.src.base + (long long)(by0 + r) * p.src.es1 + (long long)bx0 * p.src.es0;
+      for (int c = lane; c < ibw; c += 64) {
+        const float *q = g + (long long)c * NCH;
+        float *d = tile + (r * ibw + c) * TEX;
+        if constexpr (NCH == 3) {
+          float v0 = q[0], v1 = q[1], v2 = q[2];
+          *reinterpret_cast<float4 *>(d) = make_float4(v0, v1, v2, 0.0f);
+        } else if constexpr (NCH == 4) {
+          *reinterpret_cast<float4 *>(d) = *reinterpret_cast<const float4 *>(q);
+        } else if constexpr (NCH == 2) {
+          *reinterpret_cast<float2 *>(d) = *reinterpret_cast<const float2 *>(q);
+        } else {
+          d[0] = q[0];
+        }
+      }
+    }
+    __syncthreads();
+    if (hit) {
+      eu_lds_taps<NCH, TEX> lt;
+      lt.pitch = ibw * TEX;
+      lt.p0 = tile + ((iy - mny) * ibw + (ix - mnx)) * TEX;
+      eu_accumulate<NCH, DEG>(p.src.wm, tx, ty, lt, px);
+    }
+  } else if (hit) {
+    eu_global_taps<NCH> g;
+    g.es0 = p.src.es0; g.es1 = p.src.es1;
+    g.p0 = p.src.base + (long long)(ix - DEG / 2) * p.src.es0 + (long long)(iy - DEG / 2) * p.src.es1;
+    eu_accumulate<NCH, DEG>(p.src.wm, tx, ty, g, px);
+  }
+  if (!active) return;
+  if (hit && p.src.brighten != 1.0f) {
+    constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
+#pragma unroll
+    for (int c = 0; c < ncol; c++) px[c] = px[c] * p.src.brighten;
+  }
+  float *o = p.out + (long long)(y - p.row_begin) * p.out_stride + (long long)x * NCH;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) o[c] = px[c];
+}
+
+// ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
 
@@ -459,6 +239,9 @@ static hipError_t launch_nd(const eu_render_params &p, hipStream_t st)
 {
   dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(256);
   if (p.twine) hipLaunchKernelGGL((eu_render_kernel<NCH, DEG, true>), grid, block, 0, st, p);
+  else if (DEG >= 1 && p.stage == 0 && !p.direct) {
+    if constexpr (DEG >= 1) hipLaunchKernelGGL((eu_render_lds_kernel<NCH, DEG>), grid, block, 0, st, p);
+  }
   else hipLaunchKernelGGL((eu_render_kernel<NCH, DEG, false>), grid, block, 0, st, p);
   return hipGetLastError();
 }

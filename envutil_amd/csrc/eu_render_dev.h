@@ -1,0 +1,414 @@
+// Device functions of the render path (included by eu_render.hip and the
+// diagnostic kernels in eu_diag.hip). See eu_render.hip for the design notes.
+#ifndef EU_RENDER_DEV_H
+#define EU_RENDER_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <climits>
+#include "eu_device.h"
+#include "eu_math.h"
+
+#define EU_TILE_W 64
+#define EU_TILE_H 4
+
+// ---------------------------------------------------------------------------
+// gates: zimt/map.h:184-440
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float eu_vfmod(float lhs, float rhs)
+{
+  float help = lhs / rhs;
+  help = truncf(help);
+  help = help * rhs;
+  lhs = lhs - help;
+  if (fabsf(lhs) >= fabsf(rhs)) lhs = 0.0f;
+  return lhs;
+}
+
+__device__ __forceinline__ float eu_gate(float c, int kind, float lower, float upper)
+{
+  if (kind == 2) {            // periodic_gate, map.h:423-440
+    float cc = c - lower;
+    float w = upper - lower;
+    bool below = cc < 0.0f, above = cc >= w;
+    if (below || above) {
+      float cm = eu_vfmod(cc, w);
+      if (below) cm = cm + w;
+      if (cm >= w) cm = 0.0f;
+      cc = cm;
+    }
+    return cc + lower;
+  }
+  if (kind == 1) {            // mirror_gate, map.h:341-357
+    float cc = c - lower;
+    float w = upper - lower;
+    cc = fabsf(cc);
+    if (cc >= w) {
+      float cm = eu_vfmod(cc, 2 * w);
+      cm = cm - w;
+      cm = fabsf(cm);
+      cm = w - cm;
+      cc = cm;
+    }
+    return cc + lower;
+  }
+  float r = c;                // clamp_gate, map.h:231-236
+  if (c < lower) r = lower;
+  if (c > upper) r = upper;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// b-spline evaluation: split (basis.h:102-146), weights (basis.h:650-690),
+// offsets and weighted sum (eval.h:904-1059, :1237-1300)
+// ---------------------------------------------------------------------------
+
+template <int DEG>
+__device__ __forceinline__ void eu_weights(const float *wm, float delta, float *w)
+{
+  constexpr int order = DEG + 1;
+#pragma unroll
+  for (int c = 0; c <= DEG; c++) w[c] = wm[c * order];
+  float power = delta;
+#pragma unroll
+  for (int row = 1; row <= DEG; row++) {
+#pragma unroll
+    for (int c = 0; c <= DEG; c++) w[c] = w[c] + power * wm[c * order + row];
+    if (row < DEG) power = power * delta;
+  }
+}
+
+// gate + split: coordinate -> integer base position and fractional parts
+template <int DEG>
+__device__ __forceinline__ void eu_split(const eu_src_dev &s, float cx, float cy, int &ix,
+                                         int &iy, float &tx, float &ty)
+{
+  float gx = eu_gate(cx, s.gate0, s.lower0, s.upper0);
+  float gy = eu_gate(cy, s.gate1, s.lower1, s.upper1);
+  float fx = (DEG & 1) ? floorf(gx) : roundf(gx);
+  float fy = (DEG & 1) ? floorf(gy) : roundf(gy);
+  tx = gx - fx; ty = gy - fy;
+  ix = (int)fx; iy = (int)fy;
+}
+
+// tap (i, j) of the (DEG+1)^2 window straight from the braced container
+template <int NCH>
+struct eu_global_taps {
+  const float *p0; long long es0, es1;
+  __device__ __forceinline__ void load(int j, int i, float *t) const {
+    const float *q = p0 + j * es1 + i * es0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) t[c] = q[c];
+  }
+};
+
+// ... or from the workgroup's LDS copy of the source bounding box; texels are
+// padded to TEX floats so that RGB reads are one aligned ds_read_b128
+template <int NCH, int TEX>
+struct eu_lds_taps {
+  const float *p0; int pitch;       // floats
+  __device__ __forceinline__ void load(int j, int i, float *t) const {
+    const float *q = p0 + j * pitch + i * TEX;
+    if constexpr (TEX == 4) {
+      float4 v = *reinterpret_cast<const float4 *>(q);
+      t[0] = v.x; t[1] = v.y; t[2] = v.z;
+      if constexpr (NCH == 4) t[3] = v.w;
+    } else if constexpr (TEX == 2) {
+      float2 v = *reinterpret_cast<const float2 *>(q);
+      t[0] = v.x; t[1] = v.y;
+    } else {
+      t[0] = q[0];
+    }
+  }
+};
+
+// weighted sum over the window, in the reference's order (eval.h:904-1059)
+template <int NCH, int DEG, class TAPS>
+__device__ __forceinline__ void eu_accumulate(const float *wm, float tx, float ty,
+                                              const TAPS &taps, float *out)
+{
+  if constexpr (DEG == 0) {
+    taps.load(0, 0, out);
+  } else if constexpr (DEG == 1) {
+    float wl0 = 1.0f - tx, wr0 = tx, wl1 = 1.0f - ty, wr1 = ty;
+    float a[NCH], b[NCH], c2[NCH], d[NCH];
+    taps.load(0, 0, a); taps.load(0, 1, b); taps.load(1, 0, c2); taps.load(1, 1, d);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float sum = a[c] * wl0;
+      sum = sum + b[c] * wr0;
+      sum = sum * wl1;
+      float sub = c2[c] * wl0;
+      sub = sub + d[c] * wr0;
+      sum = sum + sub * wr1;
+      out[c] = sum;
+    }
+  } else {
+    constexpr int order = DEG + 1;
+    float wx[order], wy[order];
+    eu_weights<DEG>(wm, tx, wx);
+    eu_weights<DEG>(wm, ty, wy);
+    float sum[NCH];
+#pragma unroll
+    for (int j = 0; j < order; j++) {
+      float t[order][NCH];
+#pragma unroll
+      for (int i = 0; i < order; i++) taps.load(j, i, t[i]);
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        float r = t[0][c] * wx[0];
+#pragma unroll
+        for (int i = 1; i < order; i++) r = r + wx[i] * t[i][c];
+        if (j == 0) sum[c] = r * wy[0];
+        else sum[c] = sum[c] + r * wy[j];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) out[c] = sum[c];
+  }
+}
+
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_bspline(const eu_src_dev &s, float cx, float cy,
+                                           float *out)
+{
+  int ix, iy;
+  float tx, ty;
+  eu_split<DEG>(s, cx, cy, ix, iy, tx, ty);
+  eu_global_taps<NCH> g;
+  g.es0 = s.es0; g.es1 = s.es1;
+  g.p0 = s.base + (long long)(ix - DEG / 2) * s.es0 + (long long)(iy - DEG / 2) * s.es1;
+  eu_accumulate<NCH, DEG>(s.wm, tx, ty, g, out);
+}
+
+// runtime-degree evaluator for degrees above the specialised ones
+template <int NCH>
+__device__ void eu_bspline_generic(const eu_src_dev &s, float cx, float cy, float *out)
+{
+  const int d = s.degree, order = d + 1;
+  float gx = eu_gate(cx, s.gate0, s.lower0, s.upper0);
+  float gy = eu_gate(cy, s.gate1, s.lower1, s.upper1);
+  float fx = (d & 1) ? floorf(gx) : roundf(gx);
+  float fy = (d & 1) ? floorf(gy) : roundf(gy);
+  float tx = gx - fx, ty = gy - fy;
+  const float *p = s.base + (long long)(int)fx * s.es0 + (long long)(int)fy * s.es1;
+  float wx[EU_MAX_DEGREE + 1], wy[EU_MAX_DEGREE + 1];
+  for (int c = 0; c <= d; c++) { wx[c] = s.wm[c * order]; wy[c] = wx[c]; }
+  float px = tx, py = ty;
+  for (int row = 1; row <= d; row++) {
+    for (int c = 0; c <= d; c++) {
+      wx[c] = wx[c] + px * s.wm[c * order + row];
+      wy[c] = wy[c] + py * s.wm[c * order + row];
+    }
+    if (row < d) { px = px * tx; py = py * ty; }
+  }
+  const float *p0 = p - (d / 2) * s.es1 - (d / 2) * s.es0;
+  float sum[NCH];
+  for (int j = 0; j < order; j++) {
+    const float *rowp = p0 + j * s.es1;
+    for (int c = 0; c < NCH; c++) {
+      float r = rowp[c] * wx[0];
+      for (int i = 1; i < order; i++) r = r + wx[i] * rowp[i * s.es0 + c];
+      if (j == 0) sum[c] = r * wy[0];
+      else sum[c] = sum[c] + r * wy[j];
+    }
+  }
+  for (int c = 0; c < NCH; c++) out[c] = sum[c];
+}
+
+// ---------------------------------------------------------------------------
+// source lookup: ray -> source pixel coordinate
+// ---------------------------------------------------------------------------
+
+// ray_to_cubeface, geometry.h:1178-1289. The three dominance classes are
+// mutually exclusive and exhaustive; when the whole wavefront agrees (ballot)
+// only that class is evaluated - the GPU form of the reference's any_of()
+// early-outs.
+__device__ __forceinline__ void eu_cubeface(float rx, float ry, float rz,
+                                            int &face, float &in0, float &in1)
+{
+  float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+  bool m1 = ax >= ay, m2 = ax >= az, m3 = ay >= az;
+  bool domx = m1 && m2, domz = (!m2) && (!m3);
+  unsigned long long bx = __ballot(domx), bz = __ballot(domz);
+  unsigned long long act = __ballot(1);
+  if (bx == act) {
+    face = rx < 0.0f ? 0 : 1;
+    in0 = -rz / rx;
+    in1 = ry / ax;
+  } else if (bz == act) {
+    face = rz < 0.0f ? 5 : 4;
+    in0 = rx / rz;
+    in1 = ry / az;
+  } else if ((bx | bz) == 0ull) {
+    face = ry < 0.0f ? 2 : 3;
+    in0 = -rx / ay;
+    in1 = rz / ry;
+  } else {
+    // mixed wavefront near a cube edge: select per lane
+    float num0 = domx ? -rz : (domz ? rx : -rx);
+    float den0 = domx ? rx : (domz ? rz : ay);
+    float num1 = domx ? ry : (domz ? ry : rz);
+    float den1 = domx ? ax : (domz ? az : ry);
+    in0 = num0 / den0;
+    in1 = num1 / den1;
+    face = domx ? (rx < 0.0f ? 0 : 1) : (domz ? (rz < 0.0f ? 5 : 4) : (ry < 0.0f ? 2 : 3));
+  }
+}
+
+// returns false for a miss (mount_t::get_coordinate mask, environment.h:1117-1149)
+__device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float rx,
+                                                     float ry, float rz, float &sx,
+                                                     float &sy, int &face)
+{
+  face = 0;
+  if (s.prj == EU_CUBEMAP || s.prj == EU_BIATAN6) {
+    float in0, in1;
+    eu_cubeface(rx, ry, rz, face, in0, in1);
+    if (s.prj == EU_BIATAN6) {
+      const float k = (float)(4.0 / 3.14159265358979323846);
+      in0 = k * eu_atanf(in0);
+      in1 = k * eu_atanf(in1);
+    }
+    // cubemap_view_t::get_pickup_coordinate_px, environment.h:1452-1460
+    float p0 = in0 + s.refc_md, p1 = in1 + s.refc_md;
+    p0 = p0 * s.model_to_px;
+    p1 = p1 * s.model_to_px;
+    p1 = p1 + (float)(face * s.section_px);
+    sx = p0 - .5f;
+    sy = p1 - .5f;
+    return true;
+  }
+  float c0, c1;
+  switch (s.prj) {
+    case EU_SPHERICAL: {       // ray_to_ll_t, geometry.h:278-301
+      float q = sqrtf(rx * rx + rz * rz);
+      c1 = eu_atan2f(ry, q);
+      c0 = eu_atan2f(rx, rz);
+      break;
+    }
+    case EU_CYLINDRICAL: {     // ray_to_cyl_t, geometry.h:389-410
+      float q = sqrtf(rx * rx + rz * rz);
+      c1 = ry / q;
+      c0 = eu_atan2f(rx, rz);
+      break;
+    }
+    case EU_RECTILINEAR:       // ray_to_rect_t, geometry.h:328-345
+      c0 = rx / rz;
+      c1 = ry / rz;
+      break;
+    case EU_STEREOGRAPHIC: {   // ray_to_ster_t, geometry.h:445-465
+      float rn = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
+      float r = rx * rn, d = ry * rn, f = rz * rn;
+      float factor = 2.0f / (f + 1.0f);
+      c0 = r * factor;
+      c1 = d * factor;
+      break;
+    }
+    default:
+      // fisheye sources need sinf/cosf with libm's bits: next row of the plan
+      c0 = 0.0f; c1 = 0.0f;
+      break;
+  }
+  // source_t::test_crd, environment.h:970-977 (float compares)
+  bool mask = c0 >= s.wex0 && c0 <= s.wex1 && c1 >= s.wex2 && c1 <= s.wex3;
+  if (s.prj == EU_RECTILINEAR) mask = mask && (rz > 0.0f);
+  // source_t::md_to_spline, environment.h:988-1006: the subtraction is done in
+  // double (vec<float> - double), everything after it in float
+  float i0 = (float)((double)c0 - s.tex_x0);
+  i0 = i0 / s.ext_w;
+  i0 = i0 * s.total_w;
+  i0 = i0 - .5f;
+  float i1 = (float)((double)c1 - s.tex_y0);
+  i1 = i1 / s.ext_h;
+  i1 = i1 * s.total_h;
+  i1 = i1 - .5f;
+  sx = i0 - s.win_x_off;
+  sy = i1 - s.win_y_off;
+  return mask;
+}
+
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
+                                               float rz, float *px)
+{
+  float sx, sy;
+  int face;
+  bool hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+  if (hit) {
+    if constexpr (DEG >= 0) eu_bspline<NCH, DEG>(s, sx, sy, px);
+    else eu_bspline_generic<NCH>(s, sx, sy, px);
+    // environment::eval, environment.h:1821-1842
+    if (s.brighten != 1.0f) {
+      constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
+#pragma unroll
+      for (int c = 0; c < ncol; c++) px[c] = px[c] * s.brighten;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) px[c] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// target side: ray of pixel (x, y) from the stepper tables
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ void eu_ray(int form, const float *rowt, float c0, float c1,
+                                       float &rx, float &ry, float &rz)
+{
+  // rowt: A[3], B[3], C[3]
+  if (form == EU_FORM_BCA) {
+    rx = rowt[3] * c0 + rowt[6] * c1 + rowt[0];
+    ry = rowt[4] * c0 + rowt[7] * c1 + rowt[1];
+    rz = rowt[5] * c0 + rowt[8] * c1 + rowt[2];
+  } else {
+    rx = rowt[3] * c0 + rowt[0];
+    ry = rowt[4] * c0 + rowt[1];
+    rz = rowt[5] * c0 + rowt[2];
+  }
+}
+
+__device__ __forceinline__ float eu_norm3(float x, float y, float z)
+{
+  // xel.h:752-765
+  float sqn = x * x;
+  sqn = sqn + y * y;
+  sqn = sqn + z * z;
+  return sqrtf(sqn);
+}
+
+// full stepper: tables -> ray, with the normalisation flavour of the stepper
+__device__ __forceinline__ void eu_stepper(const eu_render_params &p, const float *colA,
+                                           const float *colB, const float *rowt, int x,
+                                           float &rx, float &ry, float &rz)
+{
+  eu_ray(p.form, rowt, colA[x], colB[x], rx, ry, rz);
+  if (p.norm_mode == EU_NORM_DIV) {
+    float n = eu_norm3(rx, ry, rz);
+    rx = rx / n; ry = ry / n; rz = rz / n;
+  } else if (p.norm_mode == EU_NORM_CYL) {
+    // cylindrical_stepper keeps the reciprocal length of the lane's FIRST
+    // pixel in the 512-pixel segment (stepper.h:771-775, :786)
+    int seg = (x / EU_SEGMENT) * EU_SEGMENT;
+    int x0 = seg + ((x - seg) % EU_LANES);
+    float fx, fy, fz;
+    eu_ray(p.form, rowt, colA[x0], colB[x0], fx, fy, fz);
+    float rcp = 1.0f / eu_norm3(fx, fy, fz);
+    rx = rx * rcp; ry = ry * rcp; rz = rz * rcp;
+  }
+}
+
+
+// XCD-aware tile order: blocks b and b+8 share an XCD; give each XCD a
+// contiguous run of tiles (row-major over the tile grid).
+__device__ __forceinline__ int eu_xcd_swizzle(int b, int nblk)
+{
+  const int nx = 8;
+  int per = nblk / nx, rem = nblk % nx;
+  int xcd = b % nx, k = b / nx;
+  // XCDs [0, rem) own per+1 tiles, the others per tiles
+  return xcd * per + (xcd < rem ? xcd : rem) + k;
+}
+
+#endif
