@@ -1,0 +1,52 @@
+"""envutil_amd/csrc/eu_math.h (the device's atanf/atan2f) compiled for the host
+and compared with the live libm - the library the reference's portable
+back-end calls (zimt/simd/vector_common.h:203-246). Exhaustive for atanf."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "csrc", "math_check.c")
+OUT = os.path.join(ROOT, "oracle", "_build", "libmath_check.so")
+
+
+@pytest.fixture(scope="module")
+def L():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    hdr = os.path.join(ROOT, "envutil_amd", "csrc", "eu_math.h")
+    if (not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(hdr))):
+        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC",
+                               "-shared", "-o", OUT, SRC, "-lm"])
+    lib = C.CDLL(OUT)
+    lib.check_atanf_range.restype = C.c_long
+    lib.check_atanf_range.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.check_atan2f_random.restype = C.c_long
+    lib.check_atan2f_random.argtypes = [C.c_long, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    lib.check_atan2f_pairs.restype = C.c_long
+    return lib
+
+
+def test_atanf_all_floats(L):
+    first_bad = C.c_uint32(0)
+    assert L.check_atanf_range(0, 0xFFFFFFFF, C.byref(first_bad)) == 0, hex(first_bad.value)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_atan2f_random_pairs(L, mode):
+    by, bx = C.c_float(), C.c_float()
+    bad = L.check_atan2f_random(300_000_000, 12345 + mode, mode, C.byref(by), C.byref(bx))
+    assert bad == 0, (by.value, bx.value)
+
+
+def test_atan2f_special_values(L):
+    import itertools
+    import numpy as np
+    vals = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3.4e38,
+                     -3.4e38, 0.5, 2.0, 1e30, 1e-30, 0.4375, 0.6875, 1.1875, 2.4375, 2.0 ** 25,
+                     2.0 ** -29, 2.0 ** 61, 2.0 ** -61], np.float32)
+    pairs = np.array(list(itertools.product(vals, vals)), np.float32)
+    y = np.ascontiguousarray(pairs[:, 0])
+    x = np.ascontiguousarray(pairs[:, 1])
+    assert L.check_atan2f_pairs(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), len(y)) == 0
