@@ -15,6 +15,10 @@
 
 extern "C" int eu_launch_render(const eu_render_params *p, void *stream);
 extern "C" int eu_launch_diag(const eu_render_params *p, unsigned long long *stamps_dev, void *stream);
+extern "C" int eu_launch_render2(const eu_render_params *p, void *stream);
+extern "C" int eu_verify_const_div(float c, float limit, void *stream);
+extern "C" int eu_launch_selftest(unsigned long long seed, int blocks, int iters,
+                                  unsigned long long *bad_dev, void *stream);
 extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int nch,
                                    int bc0, int bc1, int prefilter_degree, int spherical,
                                    void *stream);
@@ -127,6 +131,11 @@ void fill_src_dev(eu_source *s)
   d.total_w = (float)f.width; d.total_h = (float)f.height;
   d.win_x_off = (float)f.window_x_offset; d.win_y_off = (float)f.window_y_offset;
   d.wex0 = (float)we[0]; d.wex1 = (float)we[1]; d.wex2 = (float)we[2]; d.wex3 = (float)we[3];
+  // hits have 0 <= coordinate - extent.x0 <= extent width: verify the cheap
+  // constant division over that whole range (twice the width for slack)
+  d.rcp_ext_w = 1.0f / d.ext_w; d.rcp_ext_h = 1.0f / d.ext_h;
+  d.cdiv_ok = eu_verify_const_div(d.ext_w, 2.0f * d.ext_w, g.stream)
+           && eu_verify_const_div(d.ext_h, 2.0f * d.ext_h, g.stream);
 }
 
 int check_facet(const eu_facet *f)
@@ -258,6 +267,18 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   p->src = s->sd;
   { const char *e = getenv("EU_HIP_DIRECT"); p->direct = (e && e[0] == '1') ? 1 : 0; }
   return EU_OK;
+}
+
+// the packed two-pixel kernel where it applies, the general kernel otherwise
+// (EU_HIP_KERNEL=1 forces the general kernel: A/B switch)
+int launch_render(const eu_render_params *p, void *st)
+{
+  static const int force_v1 = [] { const char *e = getenv("EU_HIP_KERNEL"); return e && e[0] == '1'; }();
+  if (!force_v1) {
+    int rc = eu_launch_render2(p, st);
+    if (rc <= 0) return rc;
+  }
+  return eu_launch_render(p, st);
 }
 
 }  // namespace
@@ -454,14 +475,14 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   hipStream_t st = stream ? (hipStream_t)stream : g.stream;
   if (out_on_device) {
     if ((rc = build_params(trg, srcs, nsrc, out, out_row_stride_bytes, &p))) return rc;
-    if (eu_launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+    if (launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
     return EU_OK;
   }
   const size_t rows = (size_t)(trg->row_end - trg->row_begin);
   if (!rows) return EU_OK;
   if ((rc = grow(&g.stage, &g.stage_cap, rows * trg->width * och))) return rc;
   if ((rc = build_params(trg, srcs, nsrc, g.stage, min_stride, &p))) return rc;
-  if (eu_launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+  if (launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
   HIPCHK(hipMemcpy2DAsync(out, out_row_stride_bytes, g.stage, min_stride, min_stride, rows,
                           hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -488,7 +509,7 @@ int eu_hip_render_timed(const eu_target *trg, eu_source *const *srcs, int nsrc, 
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, g.stream));
   for (int i = 0; i < iters; i++)
-    if (eu_launch_render(&p, g.stream)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+    if (launch_render(&p, g.stream)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
   HIPCHK(hipEventRecord(e1, g.stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.0f;
@@ -517,6 +538,21 @@ int eu_hip_diag_stamps(const eu_target *trg, eu_source *const *srcs, int nsrc, f
     if (eu_launch_diag(&p, d, g.stream)) return fail(EU_ERR_NO_DEVICE, "diag launch failed");
   HIPCHK(hipStreamSynchronize(g.stream));
   HIPCHK(hipMemcpy(host_stamps, d, nwaves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return EU_OK;
+}
+
+// DIAGNOSTIC (not in eu_hip.h): mismatch counts {div, sqrt, atan2, const div}
+int eu_hip_selftest_math(unsigned long long seed, int blocks, int iters, unsigned long long *bad4)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  unsigned long long *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), g.stream));
+  if (eu_launch_selftest(seed, blocks, iters, d, g.stream)) return fail(EU_ERR_NO_DEVICE, "selftest launch failed");
+  HIPCHK(hipStreamSynchronize(g.stream));
+  HIPCHK(hipMemcpy(bad4, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   (void)hipFree(d);
   return EU_OK;
 }

@@ -28,6 +28,8 @@ struct eu_src_dev {
   // mount_t / source_t (environment.h:970-1006, :1117-1149)
   double tex_x0, tex_y0;     // total_extent.x0 / .y0 stay double (A.0)
   float ext_w, ext_h;        // float(x1 - x0), float(y1 - y0)
+  float rcp_ext_w, rcp_ext_h; // RN(1/ext_w), RN(1/ext_h)
+  int cdiv_ok;               // x/ext_* == the 3-op constant division for every x (verified on the device)
   float total_w, total_h;    // float(total_width), float(total_height)
   float win_x_off, win_y_off;
   float wex0, wex1, wex2, wex3;  // window extent narrowed for the compares

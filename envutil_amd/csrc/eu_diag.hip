@@ -93,3 +93,64 @@ extern "C" int eu_launch_diag(const eu_render_params *pp, unsigned long long *st
                      (hipStream_t)stream, p, stamps_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---------------------------------------------------------------------------
+// device self-tests of the range-restricted division / sqrt / packed atan2f
+// against hipcc's correctly rounded `/`, sqrtf and the scalar restatement
+// ---------------------------------------------------------------------------
+#include "eu_math2.h"
+
+__device__ __forceinline__ unsigned long long eu_mix64(unsigned long long &s)
+{
+  unsigned long long z = (s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+// a float with a random mantissa and an exponent in [2^-40, 2^40], random sign
+__device__ __forceinline__ float eu_rand_safe(unsigned r, int emin, int emax)
+{
+  unsigned e = 127 + emin + (r >> 23) % (unsigned)(emax - emin + 1);
+  return eu_u2f((r & 0x807fffffu) | (e << 23));
+}
+
+__global__ void eu_selftest_kernel(unsigned long long seed, int iters, unsigned long long *bad)
+{
+  unsigned long long s = seed + 0x1000193ull * (blockIdx.x * blockDim.x + threadIdx.x);
+  unsigned long long b_div = 0, b_sqrt = 0, b_atan2 = 0, b_cdiv = 0;
+  const float c = 6.28318548202514648f, rc = 1.0f / c;
+  for (int i = 0; i < iters; i++) {
+    unsigned long long r0 = eu_mix64(s), r1 = eu_mix64(s);
+    eu_f2 n = { eu_rand_safe((unsigned)r0, -40, 40), eu_rand_safe((unsigned)(r0 >> 32), -40, 40) };
+    eu_f2 d = { eu_rand_safe((unsigned)r1, -40, 40), eu_rand_safe((unsigned)(r1 >> 32), -40, 40) };
+    if ((i & 7) == 0) { n.x = d.x; n.y = -d.y; }                    // exact quotients
+    if ((i & 7) == 1) { n.x = eu_u2f(eu_f2u(d.x) + 1); n.y = 0.0f; } // neighbours, zero numerator
+    eu_f2 q = eu_div2_safe(n, d);
+    float q0 = n.x / d.x, q1 = n.y / d.y;
+    b_div += (eu_f2u(q.x) != eu_f2u(q0)) + (eu_f2u(q.y) != eu_f2u(q1));
+    eu_f2 a = eu_abs2(d);
+    eu_f2 sq = eu_sqrt2_safe(a);
+    b_sqrt += (eu_f2u(sq.x) != eu_f2u(sqrtf(a.x))) + (eu_f2u(sq.y) != eu_f2u(sqrtf(a.y)));
+    // ray-like operands (exponents -20..3) and the full safe range alternate
+    eu_f2 y = (i & 1) ? n : (eu_f2){ eu_rand_safe((unsigned)r0, -20, 3), eu_rand_safe((unsigned)(r0 >> 32), -20, 3) };
+    eu_f2 x = (i & 1) ? d : (eu_f2){ eu_rand_safe((unsigned)r1, -20, 3), eu_rand_safe((unsigned)(r1 >> 32), -20, 3) };
+    eu_f2 t = eu_atan2f_2(y, x);
+    b_atan2 += (eu_f2u(t.x) != eu_f2u(eu_atan2f(y.x, x.x))) + (eu_f2u(t.y) != eu_f2u(eu_atan2f(y.y, x.y)));
+    eu_f2 v = { fabsf(eu_rand_safe((unsigned)r0, -30, 3)), fabsf(eu_rand_safe((unsigned)r1, -30, 3)) };
+    eu_f2 cd = eu_div2_const(v, c, rc);
+    b_cdiv += (eu_f2u(cd.x) != eu_f2u(v.x / c)) + (eu_f2u(cd.y) != eu_f2u(v.y / c));
+  }
+  if (b_div) atomicAdd(&bad[0], b_div);
+  if (b_sqrt) atomicAdd(&bad[1], b_sqrt);
+  if (b_atan2) atomicAdd(&bad[2], b_atan2);
+  if (b_cdiv) atomicAdd(&bad[3], b_cdiv);
+}
+
+extern "C" int eu_launch_selftest(unsigned long long seed, int blocks, int iters,
+                                  unsigned long long *bad_dev, void *stream)
+{
+  hipLaunchKernelGGL(eu_selftest_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seed,
+                     iters, bad_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

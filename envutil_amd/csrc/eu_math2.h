@@ -1,0 +1,161 @@
+// Two-pixels-per-lane device math: every arithmetic step works on a float2 so
+// that hipcc emits packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32: two IEEE operations per lane per issue slot, measured 4.6 vs
+// 4.1 cycles per wave instruction, tools/ubench_valu.hip). Results are the same
+// bits as the scalar code in eu_math.h: packing changes how operations are
+// issued, never which operations are performed.
+//
+// Divisions and square roots are the expensive part of the coordinate pipeline
+// (measured 47 and 53 cycles per wave for hipcc's correctly rounded fp32 `/`
+// and sqrtf). Where the operand range is known, eu_div2_safe / eu_sqrt2_safe
+// run the SAME Newton/FMA sequence LLVM lowers `/` and sqrtf to, minus the
+// range scaling (v_div_scale, v_div_fmas' scale flag) and the special-value
+// fix-up (v_div_fixup), which are the identity for operands in the safe range.
+// tests/test_gpu_math.py checks them on the device against `/` and sqrtf.
+#ifndef EU_MATH2_H
+#define EU_MATH2_H
+
+#include "eu_math.h"
+
+typedef float eu_f2 __attribute__((ext_vector_type(2)));
+typedef int eu_i2 __attribute__((ext_vector_type(2)));
+typedef unsigned eu_u2 __attribute__((ext_vector_type(2)));
+
+#if defined(__HIPCC__)
+#define EU_D2 __host__ __device__ __forceinline__
+#else
+#define EU_D2 static inline
+#endif
+
+EU_D2 eu_f2 eu_fma2(eu_f2 a, eu_f2 b, eu_f2 c)
+{
+  return __builtin_elementwise_fma(a, b, c);
+}
+EU_D2 eu_f2 eu_abs2(eu_f2 a) { return __builtin_elementwise_abs(a); }
+EU_D2 eu_u2 eu_bits2(eu_f2 a) { return __builtin_bit_cast(eu_u2, a); }
+EU_D2 eu_f2 eu_float2(eu_u2 a) { return __builtin_bit_cast(eu_f2, a); }
+EU_D2 eu_f2 eu_sel2(eu_i2 m, eu_f2 a, eu_f2 b) { return m ? a : b; }
+
+// n / d, correctly rounded, for |n| in {0} u [2^-90, 2^90], |d| in [2^-90, 2^90]
+// (LLVM AMDGPU LowerFDIV32 without scaling and fix-up)
+EU_D2 eu_f2 eu_div2_safe(eu_f2 n, eu_f2 d)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+  // host compilation (tests): the device sequence below equals the correctly
+  // rounded quotient in the safe range, which is what `/` is on the host
+  return n / d;
+#else
+  eu_f2 r = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
+  const eu_f2 one = { 1.0f, 1.0f };
+  eu_f2 e = eu_fma2(-d, r, one);
+  r = eu_fma2(e, r, r);
+  eu_f2 q = n * r;
+  e = eu_fma2(-d, q, n);
+  q = eu_fma2(e, r, q);
+  e = eu_fma2(-d, q, n);
+  return eu_fma2(e, r, q);
+#endif
+}
+
+// sqrt(x), correctly rounded, for x in [2^-90, 2^90] (LLVM lowerFSQRTF32's
+// rsq + FMA refinement without the scaling of tiny inputs and the 0/inf select)
+EU_D2 eu_f2 eu_sqrt2_safe(eu_f2 x)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return (eu_f2){ __builtin_sqrtf(x.x), __builtin_sqrtf(x.y) };
+#else
+  eu_f2 r = { __builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y) };
+  const eu_f2 half = { 0.5f, 0.5f };
+  eu_f2 g = x * r;
+  eu_f2 h = half * r;
+  eu_f2 e = eu_fma2(-h, g, half);
+  g = eu_fma2(g, e, g);
+  h = eu_fma2(h, e, h);
+  eu_f2 dd = eu_fma2(-g, g, x);
+  return eu_fma2(dd, h, g);
+#endif
+}
+
+// x / c for a constant c with rc = RN(1/c): q = x*rc; q' = fma(fma(-q, c, x), rc, q).
+// Exact for a given c only where verified (eu_hip checks every float x of the
+// range it uses at source creation, eu_setup.hip: verify_const_div_kernel).
+EU_D2 eu_f2 eu_div2_const(eu_f2 x, float c, float rc)
+{
+  const eu_f2 cc = { c, c }, rr = { rc, rc };
+  eu_f2 q = x * rr;
+  eu_f2 r = eu_fma2(-q, cc, x);
+  return eu_fma2(r, rr, q);
+}
+
+// atanf for t >= 0 (finite or +inf), both lanes; same bits as eu_atanf.
+// One division per lane: the argument reduction of s_atanf.c is num/den with
+// (num, den) chosen by range, |t| < 7/16 uses t/1.
+EU_D2 eu_f2 eu_atanf_pos2(eu_f2 t)
+{
+  const eu_u2 it = eu_bits2(t);
+  const eu_i2 small = it < 0x3ee00000u, r0 = it < 0x3f300000u, r1 = it < 0x3f980000u,
+              r2 = it < 0x401c0000u, big = it >= 0x4c000000u;
+  const eu_f2 one = { 1.0f, 1.0f }, two = { 2.0f, 2.0f }, onep5 = { 1.5f, 1.5f },
+              mone = { -1.0f, -1.0f };
+  // id 0: (2t-1)/(2+t); 1: (t-1)/(t+1); 2: (t-1.5)/(1+1.5t); 3: -1/t; small: t/1
+  eu_f2 num = eu_sel2(small, t, eu_sel2(r0, two * t - one, eu_sel2(r1, t - one, eu_sel2(r2, t - onep5, mone))));
+  eu_f2 den = eu_sel2(small, one, eu_sel2(r0, two + t, eu_sel2(r1, t + one, eu_sel2(r2, one + onep5 * t, t))));
+  // big lanes (t >= 2^25, possibly inf) are overridden below; keep the
+  // division in range for them
+  den = eu_sel2(big, one, den);
+  eu_f2 x = eu_div2_safe(num, den);
+  const eu_f2 hi = eu_sel2(r0, (eu_f2){ 4.6364760399e-01f, 4.6364760399e-01f },
+                   eu_sel2(r1, (eu_f2){ 7.8539812565e-01f, 7.8539812565e-01f },
+                   eu_sel2(r2, (eu_f2){ 9.8279368877e-01f, 9.8279368877e-01f },
+                               (eu_f2){ 1.5707962513e+00f, 1.5707962513e+00f })));
+  const eu_f2 lo = eu_sel2(r0, (eu_f2){ 5.0121582440e-09f, 5.0121582440e-09f },
+                   eu_sel2(r1, (eu_f2){ 3.7748947079e-08f, 3.7748947079e-08f },
+                   eu_sel2(r2, (eu_f2){ 3.4473217170e-08f, 3.4473217170e-08f },
+                               (eu_f2){ 7.5497894159e-08f, 7.5497894159e-08f })));
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+              aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+              aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+              aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+  eu_f2 z = x * x;
+  eu_f2 w = z * z;
+  eu_f2 s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  eu_f2 s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  eu_f2 xs = x * (s1 + s2);
+  eu_f2 rsmall = x - xs;
+  eu_f2 rmid = hi - ((xs - lo) - x);
+  eu_f2 r = eu_sel2(small, rsmall, rmid);
+  const float hb = 1.5707962513e+00f + 7.5497894159e-08f;   // atanhi[3] + atanlo[3]
+  return eu_sel2(big, (eu_f2){ hb, hb }, r);
+}
+
+// atan2f(y, x) for both lanes; same bits as eu_atan2f (glibc 2.35 e_atan2f.c).
+// Lanes whose operands are outside [2^-40, 2^40] (zero, denormal, huge, inf,
+// NaN) take the scalar restatement; for all others e_atan2f.c reduces to
+// "z = atanf(|y/x|), then the quadrant fix" (Numerics).
+EU_D2 eu_f2 eu_atan2f_2(eu_f2 y, eu_f2 x)
+{
+  const eu_u2 hx = eu_bits2(x), hy = eu_bits2(y);
+  const eu_u2 ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+  // 2^-40 = 0x2b800000, 2^40 = 0x53800000
+  const eu_i2 okx = (ix - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 oky = (iy - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 ok = okx & oky;
+  const eu_f2 one = { 1.0f, 1.0f };
+  // out-of-range lanes divide 1/1 and are replaced afterwards
+  eu_f2 q = eu_div2_safe(eu_sel2(ok, y, one), eu_sel2(ok, x, one));
+  eu_f2 z = eu_atanf_pos2(eu_abs2(q));
+  const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const eu_i2 xneg = (eu_i2)(hx >> 31) != 0, yneg = (eu_i2)(hy >> 31) != 0;
+  // m = 0: z; 1: -z; 2: pi - (z - pi_lo); 3: (z - pi_lo) - pi
+  eu_f2 zl = z - pi_lo;
+  eu_f2 rpos = eu_sel2(yneg, -z, z);
+  eu_f2 rneg = eu_sel2(yneg, zl - pi, pi - zl);
+  eu_f2 r = eu_sel2(xneg, rneg, rpos);
+  if (__builtin_expect(!(ok.x & ok.y), 0)) {
+    if (!ok.x) r.x = eu_atan2f(y.x, x.x);
+    if (!ok.y) r.y = eu_atan2f(y.y, x.y);
+  }
+  return r;
+}
+
+#endif

@@ -459,3 +459,42 @@ extern "C" int eu_launch_cubemap_build(const float *faces, float *ir, int nch, l
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---------------------------------------------------------------------------
+// x / c by q = x*rc; q' = fma(fma(-q, c, x), rc, q): verified for EVERY float x
+// in [0, limit] against the correctly rounded quotient before the render kernel
+// is allowed to use it for this constant (environment.h:993-1000 divides every
+// source coordinate by float(extent))
+// ---------------------------------------------------------------------------
+__global__ void verify_const_div_kernel(float c, float rc, unsigned last_bits, int *bad)
+{
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  int b = 0;
+  for (; i <= last_bits; i += stride) {
+    float x = eu_u2f((unsigned)i);
+    float q = x * rc;
+    float r = fmaf(-q, c, x);
+    float q2 = fmaf(r, rc, q);
+    b |= eu_f2u(q2) != eu_f2u(x / c);
+  }
+  if (b) atomicOr(bad, 1);
+}
+
+// returns 1 when the three-operation form is exact for all x in [0, limit]
+extern "C" int eu_verify_const_div(float c, float limit, void *stream)
+{
+  if (!(c > 0.0f) || !(limit > 0.0f)) return 0;
+  int *bad = nullptr;
+  if (hipMalloc((void **)&bad, sizeof(int)) != hipSuccess) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(bad, 0, sizeof(int), st);
+  unsigned last;
+  memcpy(&last, &limit, 4);
+  hipLaunchKernelGGL(verify_const_div_kernel, dim3(256 * 8), dim3(256), 0, st, c, 1.0f / c, last, bad);
+  int h = 1;
+  if (hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) h = 1;
+  if (hipStreamSynchronize(st) != hipSuccess) h = 1;
+  (void)hipFree(bad);
+  return h ? 0 : 1;
+}
