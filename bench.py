@@ -228,7 +228,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic,
-                     "kernel": "eu_render_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "kernel": "eu_render2_kernel (packed two-pixel)" if (twine == 0 and sprj == 0 and degree in (1, 2, 3)) else "eu_render_kernel", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": alg_bytes},
     }
 

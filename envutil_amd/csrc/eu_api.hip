@@ -133,6 +133,10 @@ void fill_src_dev(eu_source *s)
   d.wex0 = (float)we[0]; d.wex1 = (float)we[1]; d.wex2 = (float)we[2]; d.wex3 = (float)we[3];
   // hits have 0 <= coordinate - extent.x0 <= extent width: verify the cheap
   // constant division over that whole range (twice the width for slack)
+  // atan2f returns values in [-0x1.921fb6p+1, 0x1.921fb6p+1]; lat = atan2f(d, s >= 0) in
+  // [-0x1.921fb6p+0, 0x1.921fb6p+0]
+  d.always_hit = f.projection == EU_SPHERICAL && d.wex0 <= -0x1.921fb6p+1f && d.wex1 >= 0x1.921fb6p+1f
+              && d.wex2 <= -0x1.921fb6p+0f && d.wex3 >= 0x1.921fb6p+0f;
   d.rcp_ext_w = 1.0f / d.ext_w; d.rcp_ext_h = 1.0f / d.ext_h;
   d.cdiv_ok = eu_verify_const_div(d.ext_w, 2.0f * d.ext_w, g.stream)
            && eu_verify_const_div(d.ext_h, 2.0f * d.ext_h, g.stream);

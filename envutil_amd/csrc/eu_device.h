@@ -29,6 +29,7 @@ struct eu_src_dev {
   double tex_x0, tex_y0;     // total_extent.x0 / .y0 stay double (A.0)
   float ext_w, ext_h;        // float(x1 - x0), float(y1 - y0)
   float rcp_ext_w, rcp_ext_h; // RN(1/ext_w), RN(1/ext_h)
+  int always_hit;            // the mask of mount_t::get_coordinate is true for every finite ray
   int cdiv_ok;               // x/ext_* == the 3-op constant division for every x (verified on the device)
   float total_w, total_h;    // float(total_width), float(total_height)
   float win_x_off, win_y_off;
@@ -49,6 +50,7 @@ struct eu_render_params {
   float *out;
   long long out_stride;      // floats per output row
   int tiles_x, tiles_y;      // grid of 64x4 tiles
+  int unit_rows;             // tile rows per XCD unit (eu_render2.hip)
   int direct;                // 1: never stage through LDS (A/B switch, EU_HIP_DIRECT=1)
   eu_src_dev src;
 };

@@ -158,4 +158,25 @@ EU_D2 eu_f2 eu_atan2f_2(eu_f2 y, eu_f2 x)
   return r;
 }
 
+// atan2f(y, x) for lanes with x > 0 known (x = sqrt(...)): only the sign of y
+// selects the quadrant
+EU_D2 eu_f2 eu_atan2f_2_xpos(eu_f2 y, eu_f2 x)
+{
+  const eu_u2 hx = eu_bits2(x), hy = eu_bits2(y);
+  const eu_u2 iy = hy & 0x7fffffffu;
+  const eu_i2 okx = (hx - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 oky = (iy - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 ok = okx & oky;
+  const eu_f2 one = { 1.0f, 1.0f };
+  eu_f2 q = eu_div2_safe(eu_sel2(ok, y, one), eu_sel2(ok, x, one));
+  eu_f2 z = eu_atanf_pos2(eu_abs2(q));
+  // m = 0: z; m = 1: z with the sign bit flipped
+  eu_f2 r = eu_float2(eu_bits2(z) ^ (hy & 0x80000000u));
+  if (__builtin_expect(!(ok.x & ok.y), 0)) {
+    if (!ok.x) r.x = eu_atan2f(y.x, x.x);
+    if (!ok.y) r.y = eu_atan2f(y.y, x.y);
+  }
+  return r;
+}
+
 #endif

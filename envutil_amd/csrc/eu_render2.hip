@@ -11,7 +11,7 @@
 
 #define EU2_TILE_W 128   // pixels of one row per wave and pass (2 per lane)
 #define EU2_TILE_H 4   // default waves (rows) per workgroup
-#define EU2_UNIT_ROWS 16  // tile rows per XCD unit
+#define EU2_UNIT_ROWS 8  // tile rows per XCD unit
 
 typedef const __attribute__((address_space(4))) float *eu_cptr;   // scalar-cache loads
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * ROWS) void eu_render2_kernel(const eu_render_p
   const int nblk = p.tiles_x * p.tiles_y;
   const int nx = 8;
   const int xcd = blockIdx.x % nx, kblk = blockIdx.x / nx;
-  const int unit_tiles = EU2_UNIT_ROWS * p.tiles_x;
+  const int unit_tiles = p.unit_rows * p.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   {
@@ -181,11 +181,15 @@ __global__ __launch_bounds__(64 * ROWS) void eu_render2_kernel(const eu_render_p
       if (!ok.y) qs.y = sqrtf(q2.y);
     }
   }
-  eu_f2 lat = eu_atan2f_2(ry, qs);
+  eu_f2 lat = eu_atan2f_2_xpos(ry, qs);
   eu_f2 lon = eu_atan2f_2(rx, rz);
 
   // mount_t::get_coordinate mask (environment.h:1117-1149)
-  eu_i2 hit = (lon >= s.wex0) & (lon <= s.wex1) & (lat >= s.wex2) & (lat <= s.wex3);
+  // a full-sphere image covers atan2f's whole range [-pi_f, pi_f] x [-pi_f/2, pi_f/2]
+  // (the window extents narrow to exactly those floats): every ray hits
+  eu_i2 hit = { -1, -1 };
+  if (!s.always_hit)
+    hit = (lon >= s.wex0) & (lon <= s.wex1) & (lat >= s.wex2) & (lat <= s.wex3);
 
   // source_t::md_to_spline (environment.h:988-1006)
   eu_f2 i0 = { (float)((double)lon.x - s.tex_x0), (float)((double)lon.y - s.tex_x0) };
@@ -255,8 +259,8 @@ __global__ __launch_bounds__(64 * ROWS) void eu_render2_kernel(const eu_render_p
 template <int NCH, int ROWS, bool PERSIST, int PASSES>
 static int launch2_nr(const eu_render_params &p, hipStream_t st)
 {
-  const int unit_tiles = EU2_UNIT_ROWS * p.tiles_x;
-  const int units = (p.tiles_y + EU2_UNIT_ROWS - 1) / EU2_UNIT_ROWS;
+  const int unit_tiles = p.unit_rows * p.tiles_x;
+  const int units = (p.tiles_y + p.unit_rows - 1) / p.unit_rows;
   int g = ((units + 7) / 8) * 8 * unit_tiles;
   dim3 grid((unsigned)g), block(64 * ROWS);
   switch (p.src.degree) {
@@ -273,6 +277,8 @@ static int launch2_n(eu_render_params &p, hipStream_t st)
 {
   static const int rows = [] { const char *e = getenv("EU_HIP_ROWS"); return e ? atoi(e) : EU2_TILE_H; }();
   static const int persist = [] { const char *e = getenv("EU_HIP_PERSIST"); return e ? atoi(e) : 0; }();
+  static const int unit_rows = [] { const char *e = getenv("EU_HIP_UNIT"); return e ? atoi(e) : EU2_UNIT_ROWS; }();
+  p.unit_rows = unit_rows > 0 ? unit_rows : EU2_UNIT_ROWS;
   static const int passes = [] { const char *e = getenv("EU_HIP_PASSES"); return e ? atoi(e) : 1; }();
   p.tiles_y = (p.row_end - p.row_begin + rows - 1) / rows;
   if (passes == 2) {

@@ -65,6 +65,13 @@ long check_atan2f_2_random(long n, uint64_t seed, int mode)
       eu_f2 r = eu_atan2f_2(y, x);
       if (!same(r.x, atan2f(v[0], v[1]))) bad++;
       if (!same(r.y, atan2f(v[2], v[3]))) bad++;
+      /* the x > 0 form */
+      eu_f2 xp = { fabsf(v[1]), fabsf(v[3]) };
+      if (xp.x > 0.0f && xp.y > 0.0f && xp.x == xp.x && xp.y == xp.y) {
+        r = eu_atan2f_2_xpos(y, xp);
+        if (!same(r.x, atan2f(v[0], xp.x))) bad++;
+        if (!same(r.y, atan2f(v[2], xp.y))) bad++;
+      }
     }
   }
   return bad;
