@@ -16,8 +16,8 @@ __global__ __launch_bounds__(256) void eu_diag_kernel(const eu_render_params p,
   __builtin_amdgcn_sched_barrier(0);
   unsigned long long t0 = eu_stamp();
   __builtin_amdgcn_sched_barrier(0);
-  const int nblk = p.tiles_x * p.tiles_y;
-  int b = eu_xcd_swizzle(blockIdx.x, nblk);
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
+  if (b < 0) return;
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wrow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -89,7 +89,7 @@ extern "C" int eu_launch_diag(const eu_render_params *pp, unsigned long long *st
   eu_render_params p = *pp;
   p.tiles_x = (p.width + EU_TILE_W - 1) / EU_TILE_W;
   p.tiles_y = (p.row_end - p.row_begin + EU_TILE_H - 1) / EU_TILE_H;
-  hipLaunchKernelGGL(eu_diag_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(256), 0,
+  hipLaunchKernelGGL(eu_diag_kernel, dim3((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), dim3(256), 0,
                      (hipStream_t)stream, p, stamps_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

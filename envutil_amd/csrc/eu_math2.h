@@ -35,6 +35,7 @@ EU_D2 eu_f2 eu_abs2(eu_f2 a) { return __builtin_elementwise_abs(a); }
 EU_D2 eu_u2 eu_bits2(eu_f2 a) { return __builtin_bit_cast(eu_u2, a); }
 EU_D2 eu_f2 eu_float2(eu_u2 a) { return __builtin_bit_cast(eu_f2, a); }
 EU_D2 eu_f2 eu_sel2(eu_i2 m, eu_f2 a, eu_f2 b) { return m ? a : b; }
+EU_D2 eu_i2 eu_sel2i(eu_i2 m, eu_i2 a, eu_i2 b) { return m ? a : b; }
 
 // n / d, correctly rounded, for |n| in {0} u [2^-90, 2^90], |d| in [2^-90, 2^90]
 // (LLVM AMDGPU LowerFDIV32 without scaling and fix-up)

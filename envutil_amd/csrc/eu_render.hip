@@ -36,18 +36,8 @@
 template <int NCH, int DEG, bool TWINE>
 __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p)
 {
-  // XCD-aware tile order: blocks b and b+8 share an XCD; give each XCD a
-  // contiguous run of tiles (row-major over the tile grid).
-  const int nblk = p.tiles_x * p.tiles_y;
-  int b = blockIdx.x;
-  {
-    const int nx = 8;
-    int per = nblk / nx, rem = nblk % nx;
-    int xcd = b % nx, k = b / nx;
-    // XCDs [0, rem) own per+1 tiles, the others per tiles
-    int start = xcd * per + (xcd < rem ? xcd : rem);
-    b = start + k;
-  }
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
+  if (b < 0) return;
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wrow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -138,14 +128,8 @@ __global__ __launch_bounds__(256) void eu_render_lds_kernel(const eu_render_para
   __shared__ __attribute__((aligned(16))) float tile[CAP * TEX];
   __shared__ int bbw[4][4];
 
-  const int nblk = p.tiles_x * p.tiles_y;
-  int b = blockIdx.x;
-  {
-    const int nx = 8;
-    int per = nblk / nx, rem = nblk % nx;
-    int xcd = b % nx, k = b / nx;
-    b = xcd * per + (xcd < rem ? xcd : rem) + k;
-  }
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
+  if (b < 0) return;   // whole workgroup: no barrier is skipped by a part of it
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -237,7 +221,7 @@ __global__ __launch_bounds__(256) void eu_render_lds_kernel(const eu_render_para
 template <int NCH, int DEG>
 static hipError_t launch_nd(const eu_render_params &p, hipStream_t st)
 {
-  dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(256);
+  dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), block(256);
   if (p.twine) hipLaunchKernelGGL((eu_render_kernel<NCH, DEG, true>), grid, block, 0, st, p);
   else if (DEG >= 1 && p.stage == 0 && !p.direct) {
     if constexpr (DEG >= 1) hipLaunchKernelGGL((eu_render_lds_kernel<NCH, DEG>), grid, block, 0, st, p);

@@ -122,89 +122,152 @@ __device__ __forceinline__ eu_f2 eu_gate2(eu_f2 c, int kind, float lower, float 
   return r;
 }
 
-template <int NCH, int DEG, int ROWS, bool PERSIST, int PASSES>
-__global__ __launch_bounds__(64 * ROWS) void eu_render2_kernel(const eu_render_params p)
+// ---------------------------------------------------------------------------
+// both lanes: rays from the stepper tables
+// ---------------------------------------------------------------------------
+
+struct eu_ray2 { eu_f2 x, y, z; };
+
+// rowt: A[3], B[3], C[3] of one stepper (scalar-cache loads, wave-uniform)
+__device__ __forceinline__ eu_ray2 eu_rays2(int form, int norm_mode, eu_cptr rowt,
+                                            const float *__restrict__ colA,
+                                            const float *__restrict__ colB, int xa, int xb)
 {
-  // XCD-aware tile order. Workgroups b and b+8 share an XCD (round-robin
-  // dispatch). Tiles are grouped into units of EU2_UNIT_ROWS tile rows; unit u
-  // belongs to XCD u % 8, and an XCD walks its units in order. Inside a unit
-  // consecutive workgroups of one XCD are neighbouring tiles (L2 reuse of the
-  // source rows they share); across the frame every XCD gets a slice of every
-  // cube face, so the slower polar faces do not all land on two XCDs.
-  const int nblk = p.tiles_x * p.tiles_y;
-  const int nx = 8;
-  const int xcd = blockIdx.x % nx, kblk = blockIdx.x / nx;
-  const int unit_tiles = p.unit_rows * p.tiles_x;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  {
-  const int ul = kblk / unit_tiles, iu = kblk - ul * unit_tiles;
-  const int b = (ul * nx + xcd) * unit_tiles + iu;
-  if (b >= nblk) return;
-  const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
-  const int y = p.row_begin + tile_y * ROWS + wave;
-  if (y >= p.row_end) return;
-#pragma unroll 1
-  for (int pass = 0; pass < PASSES; pass++) {
-  const int xa = (tile_x * PASSES + pass) * EU2_TILE_W + lane, xb = xa + 64;
-  if (xa >= p.width) continue;
-  const bool vb = xb < p.width;
-  const int xbc = vb ? xb : xa;
-
-  // stepper tables -> rays (stepper.h; eu_setup_math.h build_stepper_tables)
-  eu_cptr rowt = (eu_cptr)(p.row + (long long)y * EU_ROW_FLOATS);
   const float A0 = rowt[0], A1 = rowt[1], A2 = rowt[2], B0 = rowt[3], B1 = rowt[4], B2 = rowt[5];
-  const eu_f2 c0 = { p.col[xa], p.col[xbc] };
-  eu_f2 rx, ry, rz;
-  if (p.form == EU_FORM_BCA) {
-    const float C0 = rowt[6], C1 = rowt[7], C2 = rowt[8];
-    const eu_f2 c1 = { p.col[p.width + xa], p.col[p.width + xbc] };
-    rx = B0 * c0 + C0 * c1 + A0;
-    ry = B1 * c0 + C1 * c1 + A1;
-    rz = B2 * c0 + C2 * c1 + A2;
+  const eu_f2 c0 = { colA[xa], colA[xb] };
+  eu_ray2 r;
+  float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+  eu_f2 c1 = { 0.0f, 0.0f };
+  if (form == EU_FORM_BCA) {
+    C0 = rowt[6]; C1 = rowt[7]; C2 = rowt[8];
+    c1 = (eu_f2){ colB[xa], colB[xb] };
+    r.x = B0 * c0 + C0 * c1 + A0;
+    r.y = B1 * c0 + C1 * c1 + A1;
+    r.z = B2 * c0 + C2 * c1 + A2;
   } else {
-    rx = B0 * c0 + A0;
-    ry = B1 * c0 + A1;
-    rz = B2 * c0 + A2;
+    r.x = B0 * c0 + A0;
+    r.y = B1 * c0 + A1;
+    r.z = B2 * c0 + A2;
   }
+  if (norm_mode == EU_NORM_DIV) {
+    // trg /= norm(trg), xel.h:752-765 (rectilinear / cubemap / biatan6 steppers
+    // with normalize = true)
+    eu_f2 sqn = r.x * r.x; sqn = sqn + r.y * r.y; sqn = sqn + r.z * r.z;
+    eu_f2 n = { sqrtf(sqn.x), sqrtf(sqn.y) };
+    r.x = r.x / n; r.y = r.y / n; r.z = r.z / n;
+  } else if (norm_mode == EU_NORM_CYL) {
+    // cylindrical_stepper: reciprocal length of the lane's FIRST pixel in the
+    // 512-pixel segment (stepper.h:771-775, :786)
+    int sa = (xa / EU_SEGMENT) * EU_SEGMENT, sb = (xb / EU_SEGMENT) * EU_SEGMENT;
+    int fa = sa + ((xa - sa) % EU_LANES), fb = sb + ((xb - sb) % EU_LANES);
+    const eu_f2 d0 = { colA[fa], colA[fb] }, d1 = { colB[fa], colB[fb] };
+    eu_f2 fx = B0 * d0 + C0 * d1 + A0, fy = B1 * d0 + C1 * d1 + A1, fz = B2 * d0 + C2 * d1 + A2;
+    eu_f2 sqn = fx * fx; sqn = sqn + fy * fy; sqn = sqn + fz * fz;
+    eu_f2 rcp = { 1.0f / sqrtf(sqn.x), 1.0f / sqrtf(sqn.y) };
+    r.x = r.x * rcp; r.y = r.y * rcp; r.z = r.z * rcp;
+  }
+  return r;
+}
 
-  // ray_to_ll_t (geometry.h:278-301): s = sqrt(r*r + f*f); lat = atan2(d, s); lon = atan2(r, f)
-  const eu_src_dev &s = p.src;
-  eu_f2 q2 = rx * rx + rz * rz;
-  eu_f2 qs;
-  {
-    const eu_u2 iq = eu_bits2(q2);
-    const eu_i2 ok = (iq - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
-    qs = eu_sqrt2_safe(eu_sel2(ok, q2, (eu_f2){ 1.0f, 1.0f }));
-    if (__builtin_expect(!(ok.x & ok.y), 0)) {
-      if (!ok.x) qs.x = sqrtf(q2.x);
-      if (!ok.y) qs.y = sqrtf(q2.y);
+// ---------------------------------------------------------------------------
+// both lanes: ray -> source pixel coordinate (+ hit mask)
+// ---------------------------------------------------------------------------
+
+// x / y for lanes where y dominates: |x| <= |y|. Range-checked FMA division,
+// true division for the rest.
+__device__ __forceinline__ eu_f2 eu_div2_guarded(eu_f2 n, eu_f2 d)
+{
+  const eu_u2 in = eu_bits2(n) & 0x7fffffffu, id = eu_bits2(d) & 0x7fffffffu;
+  // d in [2^-40, 2^40]; n zero or >= 2^-80
+  const eu_i2 okd = (id - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 okn = (in == 0u) | ((in - 0x17800000u) <= (0x53800000u - 0x17800000u));
+  const eu_i2 ok = okd & okn;
+  const eu_f2 one = { 1.0f, 1.0f };
+  eu_f2 q = eu_div2_safe(eu_sel2(ok, n, one), eu_sel2(ok, d, one));
+  if (__builtin_expect(!(ok.x & ok.y), 0)) {
+    if (!ok.x) q.x = n.x / d.x;
+    if (!ok.y) q.y = n.y / d.y;
+  }
+  return q;
+}
+
+template <int PRJ>
+__device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r, eu_f2 &sx,
+                                           eu_f2 &sy)
+{
+  if constexpr (PRJ == EU_CUBEMAP || PRJ == EU_BIATAN6) {
+    // ray_to_cubeface, geometry.h:1178-1289 (dominance classes by select)
+    const eu_f2 ax = eu_abs2(r.x), ay = eu_abs2(r.y), az = eu_abs2(r.z);
+    const eu_i2 m1 = ax >= ay, m2 = ax >= az, m3 = ay >= az;
+    const eu_i2 domx = m1 & m2, domz = (~m2) & (~m3);
+    const eu_f2 num0 = eu_sel2(domx, -r.z, eu_sel2(domz, r.x, -r.x));
+    const eu_f2 den0 = eu_sel2(domx, r.x, eu_sel2(domz, r.z, ay));
+    const eu_f2 num1 = eu_sel2(domx, r.y, eu_sel2(domz, r.y, r.z));
+    const eu_f2 den1 = eu_sel2(domx, ax, eu_sel2(domz, az, r.y));
+    eu_f2 in0 = eu_div2_guarded(num0, den0), in1 = eu_div2_guarded(num1, den1);
+    const eu_i2 fx = eu_sel2i(r.x < 0.0f, 0, 1), fz = eu_sel2i(r.z < 0.0f, 5, 4),
+                fy = eu_sel2i(r.y < 0.0f, 2, 3);
+    const eu_i2 face = eu_sel2i(domx, fx, eu_sel2i(domz, fz, fy));
+    if constexpr (PRJ == EU_BIATAN6) {
+      // in_face = float(4/pi) * atan(in_face), environment.h:1480; atanf is odd
+      const float k = (float)(4.0 / 3.14159265358979323846);
+      eu_f2 a0 = eu_atanf_pos2(eu_abs2(in0)), a1 = eu_atanf_pos2(eu_abs2(in1));
+      a0 = eu_float2(eu_bits2(a0) | (eu_bits2(in0) & 0x80000000u));
+      a1 = eu_float2(eu_bits2(a1) | (eu_bits2(in1) & 0x80000000u));
+      in0 = k * a0; in1 = k * a1;
     }
-  }
-  eu_f2 lat = eu_atan2f_2_xpos(ry, qs);
-  eu_f2 lon = eu_atan2f_2(rx, rz);
-
-  // mount_t::get_coordinate mask (environment.h:1117-1149)
-  // a full-sphere image covers atan2f's whole range [-pi_f, pi_f] x [-pi_f/2, pi_f/2]
-  // (the window extents narrow to exactly those floats): every ray hits
-  eu_i2 hit = { -1, -1 };
-  if (!s.always_hit)
-    hit = (lon >= s.wex0) & (lon <= s.wex1) & (lat >= s.wex2) & (lat <= s.wex3);
-
-  // source_t::md_to_spline (environment.h:988-1006)
-  eu_f2 i0 = { (float)((double)lon.x - s.tex_x0), (float)((double)lon.y - s.tex_x0) };
-  eu_f2 i1 = { (float)((double)lat.x - s.tex_y0), (float)((double)lat.y - s.tex_y0) };
-  if (s.cdiv_ok) {
-    i0 = eu_div2_const(i0, s.ext_w, s.rcp_ext_w);
-    i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
+    // cubemap_view_t::get_pickup_coordinate_px, environment.h:1452-1460
+    eu_f2 p0 = in0 + s.refc_md, p1 = in1 + s.refc_md;
+    p0 = p0 * s.model_to_px; p1 = p1 * s.model_to_px;
+    const eu_i2 fs = face * s.section_px;
+    p1 = p1 + (eu_f2){ (float)fs.x, (float)fs.y };
+    sx = p0 - .5f; sy = p1 - .5f;
+    return (eu_i2){ -1, -1 };
   } else {
-    i0 = i0 / s.ext_w;
-    i1 = i1 / s.ext_h;
+    // ray_to_ll_t (geometry.h:278-301): s = sqrt(r*r + f*f); lat = atan2(d, s); lon = atan2(r, f)
+    eu_f2 q2 = r.x * r.x + r.z * r.z;
+    eu_f2 qs;
+    {
+      const eu_u2 iq = eu_bits2(q2);
+      const eu_i2 ok = (iq - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+      qs = eu_sqrt2_safe(eu_sel2(ok, q2, (eu_f2){ 1.0f, 1.0f }));
+      if (__builtin_expect(!(ok.x & ok.y), 0)) {
+        if (!ok.x) qs.x = sqrtf(q2.x);
+        if (!ok.y) qs.y = sqrtf(q2.y);
+      }
+    }
+    // s == 0 (ray along the vertical axis) fails the range check and takes the scalar path
+    eu_f2 lat = eu_atan2f_2_xpos(r.y, qs);
+    eu_f2 lon = eu_atan2f_2(r.x, r.z);
+    // a full-sphere image covers atan2f's whole range: every ray hits
+    eu_i2 hit = { -1, -1 };
+    if (!s.always_hit)
+      hit = (lon >= s.wex0) & (lon <= s.wex1) & (lat >= s.wex2) & (lat <= s.wex3);
+    // source_t::md_to_spline (environment.h:988-1006)
+    eu_f2 i0 = { (float)((double)lon.x - s.tex_x0), (float)((double)lon.y - s.tex_x0) };
+    eu_f2 i1 = { (float)((double)lat.x - s.tex_y0), (float)((double)lat.y - s.tex_y0) };
+    if (s.cdiv_ok) {
+      i0 = eu_div2_const(i0, s.ext_w, s.rcp_ext_w);
+      i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
+    } else {
+      i0 = i0 / s.ext_w;
+      i1 = i1 / s.ext_h;
+    }
+    i0 = i0 * s.total_w; i0 = i0 - .5f;
+    i1 = i1 * s.total_h; i1 = i1 - .5f;
+    sx = i0 - s.win_x_off; sy = i1 - s.win_y_off;
+    return hit;
   }
-  i0 = i0 * s.total_w; i0 = i0 - .5f;
-  i1 = i1 * s.total_h; i1 = i1 - .5f;
-  eu_f2 sx = i0 - s.win_x_off, sy = i1 - s.win_y_off;
+}
 
+// ---------------------------------------------------------------------------
+// both lanes: b-spline evaluation at (sx, sy); misses give 0
+// ---------------------------------------------------------------------------
+
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_eval2(const eu_src_dev &s, eu_f2 sx, eu_f2 sy, eu_i2 hit,
+                                         float *pxa, float *pxb)
+{
   // gate + split (map.h, basis.h:102-146)
   eu_f2 gx = eu_gate2(sx, s.gate0, s.lower0, s.upper0);
   eu_f2 gy = eu_gate2(sy, s.gate1, s.lower1, s.upper1);
@@ -215,7 +278,6 @@ __global__ __launch_bounds__(64 * ROWS) void eu_render2_kernel(const eu_render_p
     fx = (eu_f2){ roundf(gx.x), roundf(gx.y) }; fy = (eu_f2){ roundf(gy.x), roundf(gy.y) };
   }
   const eu_f2 tx = gx - fx, ty = gy - fy;
-
   constexpr int order = DEG + 1;
   eu_f2 wx[order], wy[order];
   if constexpr (DEG >= 2) {
@@ -228,83 +290,130 @@ __global__ __launch_bounds__(64 * ROWS) void eu_render2_kernel(const eu_render_p
     if constexpr (DEG >= 2) { wxa[i] = wx[i].x; wxb[i] = wx[i].y; wya[i] = wy[i].x; wyb[i] = wy[i].y; }
     else { wxa[i] = wxb[i] = wya[i] = wyb[i] = 0.0f; }
   }
-
-  const float *pa = s.base + (long long)((int)fx.x - DEG / 2) * NCH + (long long)((int)fy.x - DEG / 2) * s.es1;
-  const float *pb = s.base + (long long)((int)fx.y - DEG / 2) * NCH + (long long)((int)fy.y - DEG / 2) * s.es1;
-  float pxa[NCH], pxb[NCH];
+  // a missed lane's coordinate is arbitrary (the reference evaluates it at an
+  // uninitialised but gated position and zeroes the result): keep its address
+  // inside the container
+  const int ixa = hit.x ? (int)fx.x : 0, iya = hit.x ? (int)fy.x : 0;
+  const int ixb = hit.y ? (int)fx.y : 0, iyb = hit.y ? (int)fy.y : 0;
+  const float *pa = s.base + (long long)(ixa - DEG / 2) * NCH + (long long)(iya - DEG / 2) * s.es1;
+  const float *pb = s.base + (long long)(ixb - DEG / 2) * NCH + (long long)(iyb - DEG / 2) * s.es1;
   eu_accumulate1<NCH, DEG>(pa, s.es1, wxa, wya, tx.x, ty.x, pxa);
   eu_accumulate1<NCH, DEG>(pb, s.es1, wxb, wyb, tx.y, ty.y, pxb);
-
+  // environment::eval brighten (environment.h:1821-1842), zero on a miss
   constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
   const bool bright = s.brighten != 1.0f;
-  float *o = p.out + (long long)(y - p.row_begin) * p.out_stride;
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    float v = pxa[c];
-    if (bright && c < ncol) v = v * s.brighten;
-    o[(long long)xa * NCH + c] = hit.x ? v : 0.0f;
-  }
-  if (vb) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      float v = pxb[c];
-      if (bright && c < ncol) v = v * s.brighten;
-      o[(long long)xb * NCH + c] = hit.y ? v : 0.0f;
-    }
-  }
-  }  // passes
+    float va = pxa[c], vb = pxb[c];
+    if (bright && c < ncol) { va = va * s.brighten; vb = vb * s.brighten; }
+    pxa[c] = hit.x ? va : 0.0f;
+    pxb[c] = hit.y ? vb : 0.0f;
   }
 }
 
-template <int NCH, int ROWS, bool PERSIST, int PASSES>
-static int launch2_nr(const eu_render_params &p, hipStream_t st)
+// ---------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------
+
+template <int NCH, int DEG, int PRJ, bool TWINE>
+__global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params p)
 {
-  const int unit_tiles = p.unit_rows * p.tiles_x;
-  const int units = (p.tiles_y + p.unit_rows - 1) / p.unit_rows;
-  int g = ((units + 7) / 8) * 8 * unit_tiles;
-  dim3 grid((unsigned)g), block(64 * ROWS);
-  switch (p.src.degree) {
-    case 1: hipLaunchKernelGGL((eu_render2_kernel<NCH, 1, ROWS, PERSIST, PASSES>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((eu_render2_kernel<NCH, 2, ROWS, PERSIST, PASSES>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((eu_render2_kernel<NCH, 3, ROWS, PERSIST, PASSES>), grid, block, 0, st, p); break;
-    default: return 1;
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, p.unit_rows);
+  if (b < 0) return;
+  const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int y = p.row_begin + tile_y * EU2_TILE_H + wave;
+  if (y >= p.row_end) return;
+  const int xa = tile_x * EU2_TILE_W + lane, xb = xa + 64;
+  if (xa >= p.width) return;
+  const bool vb = xb < p.width;
+  const int xbc = vb ? xb : xa;
+  const eu_src_dev &s = p.src;
+
+  eu_cptr rowt = (eu_cptr)(p.row + (long long)y * EU_ROW_FLOATS);
+  const eu_ray2 r00 = eu_rays2(p.form, p.norm_mode, rowt, p.col, p.col + p.width, xa, xbc);
+
+  float pxa[NCH], pxb[NCH];
+  if constexpr (!TWINE) {
+    eu_f2 sx, sy;
+    const eu_i2 hit = eu_coord2<PRJ>(s, r00, sx, sy);
+    eu_eval2<NCH, DEG>(s, sx, sy, hit, pxa, pxb);
+  } else {
+    // deriv_stepper (stepper.h:1591-1715) + twine_t::eval (twining.h:128-263)
+    const eu_ray2 r10 = eu_rays2(p.form, p.norm_mode, rowt, p.col + 2 * p.width,
+                                 p.col + 3 * p.width, xa, xbc);
+    const eu_ray2 r01 = eu_rays2(p.form, p.norm_mode, rowt + 9, p.col, p.col + p.width, xa, xbc);
+    const eu_f2 dxx = r10.x - r00.x, dxy = r10.y - r00.y, dxz = r10.z - r00.z;
+    const eu_f2 dyx = r01.x - r00.x, dyy = r01.y - r00.y, dyz = r01.z - r00.z;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) { pxa[c] = 0.0f; pxb[c] = 0.0f; }
+    eu_cptr taps = (eu_cptr)p.taps;
+    for (int k = 0; k < p.ntaps; k++) {
+      const float cx = taps[3 * k], cy = taps[3 * k + 1], cw = taps[3 * k + 2];
+      eu_ray2 rk;
+      rk.x = r00.x + cx * dxx + cy * dyx;
+      rk.y = r00.y + cx * dxy + cy * dyy;
+      rk.z = r00.z + cx * dxz + cy * dyz;
+      eu_f2 sx, sy;
+      const eu_i2 hit = eu_coord2<PRJ>(s, rk, sx, sy);
+      float qa[NCH], qb[NCH];
+      eu_eval2<NCH, DEG>(s, sx, sy, hit, qa, qb);
+#pragma unroll
+      for (int c = 0; c < NCH; c++) { pxa[c] = pxa[c] + cw * qa[c]; pxb[c] = pxb[c] + cw * qb[c]; }
+    }
   }
+
+  float *o = p.out + (long long)(y - p.row_begin) * p.out_stride;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) o[(long long)xa * NCH + c] = pxa[c];
+  if (vb) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) o[(long long)xb * NCH + c] = pxb[c];
+  }
+}
+
+template <int NCH, int DEG, int PRJ>
+static int launch2_ndp(const eu_render_params &p, hipStream_t st)
+{
+  dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, p.unit_rows)), block(256);
+  if (p.twine) hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, false>), grid, block, 0, st, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int NCH>
-static int launch2_n(eu_render_params &p, hipStream_t st)
+template <int NCH, int DEG>
+static int launch2_nd(const eu_render_params &p, hipStream_t st)
 {
-  static const int rows = [] { const char *e = getenv("EU_HIP_ROWS"); return e ? atoi(e) : EU2_TILE_H; }();
-  static const int persist = [] { const char *e = getenv("EU_HIP_PERSIST"); return e ? atoi(e) : 0; }();
-  static const int unit_rows = [] { const char *e = getenv("EU_HIP_UNIT"); return e ? atoi(e) : EU2_UNIT_ROWS; }();
-  p.unit_rows = unit_rows > 0 ? unit_rows : EU2_UNIT_ROWS;
-  static const int passes = [] { const char *e = getenv("EU_HIP_PASSES"); return e ? atoi(e) : 1; }();
-  p.tiles_y = (p.row_end - p.row_begin + rows - 1) / rows;
-  if (passes == 2) {
-    p.tiles_x = (p.width + 2 * EU2_TILE_W - 1) / (2 * EU2_TILE_W);
-    if (rows == 8) return launch2_nr<NCH, 8, false, 2>(p, st);
-    p.tiles_y = (p.row_end - p.row_begin + 3) / 4;
-    return launch2_nr<NCH, 4, false, 2>(p, st);
+  switch (p.src.prj) {
+    case EU_SPHERICAL: return launch2_ndp<NCH, DEG, EU_SPHERICAL>(p, st);
+    case EU_CUBEMAP: return launch2_ndp<NCH, DEG, EU_CUBEMAP>(p, st);
+    case EU_BIATAN6: return launch2_ndp<NCH, DEG, EU_BIATAN6>(p, st);
   }
-  if (passes == 4) {
-    p.tiles_x = (p.width + 4 * EU2_TILE_W - 1) / (4 * EU2_TILE_W);
-    p.tiles_y = (p.row_end - p.row_begin + 3) / 4;
-    return launch2_nr<NCH, 4, false, 4>(p, st);
-  }
-  switch (rows) {
-    case 8: return launch2_nr<NCH, 8, false, 1>(p, st);
-    case 16: return launch2_nr<NCH, 16, false, 1>(p, st);
-    default: p.tiles_y = (p.row_end - p.row_begin + 3) / 4; return launch2_nr<NCH, 4, false, 1>(p, st);
-  }
+  return 1;
 }
 
-// returns 1 when the job is outside this kernel's coverage (caller falls back)
+template <int NCH>
+static int launch2_n(const eu_render_params &p, hipStream_t st)
+{
+  switch (p.src.degree) {
+    case 1: return launch2_nd<NCH, 1>(p, st);
+    case 2: return launch2_nd<NCH, 2>(p, st);
+    case 3: return launch2_nd<NCH, 3>(p, st);
+  }
+  return 1;
+}
+
+// returns 1 when the job is outside this kernel's coverage (caller falls back
+// to eu_render_kernel)
 extern "C" int eu_launch_render2(const eu_render_params *pp, void *stream)
 {
   eu_render_params p = *pp;
-  if (p.twine || p.stage != 0 || p.norm_mode != EU_NORM_NONE || p.src.prj != EU_SPHERICAL) return 1;
+  if (p.stage != 0) return 1;
+  if (p.src.prj != EU_SPHERICAL && p.src.prj != EU_CUBEMAP && p.src.prj != EU_BIATAN6) return 1;
   if (p.src.degree < 1 || p.src.degree > 3 || p.src.es0 != p.nch) return 1;
+  static const int unit_rows = [] { const char *e = getenv("EU_HIP_UNIT"); return e ? atoi(e) : EU2_UNIT_ROWS; }();
+  p.unit_rows = unit_rows > 0 ? unit_rows : EU2_UNIT_ROWS;
   p.tiles_x = (p.width + EU2_TILE_W - 1) / EU2_TILE_W;
   p.tiles_y = (p.row_end - p.row_begin + EU2_TILE_H - 1) / EU2_TILE_H;
   if (p.tiles_x <= 0 || p.tiles_y <= 0) return 0;

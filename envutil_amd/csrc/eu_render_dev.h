@@ -400,15 +400,29 @@ __device__ __forceinline__ void eu_stepper(const eu_render_params &p, const floa
 }
 
 
-// XCD-aware tile order: blocks b and b+8 share an XCD; give each XCD a
-// contiguous run of tiles (row-major over the tile grid).
-__device__ __forceinline__ int eu_xcd_swizzle(int b, int nblk)
+// XCD-aware tile order. Workgroups b and b+8 share an XCD (round-robin
+// dispatch). Tiles are grouped into units of unit_rows tile rows; unit u
+// belongs to XCD u % 8 and an XCD walks its units in order: consecutive
+// workgroups of one XCD are neighbouring tiles (they share source rows in
+// that XCD's L2), while every XCD gets a slice of every part of the frame
+// (cube faces differ in cost). Returns the tile index or -1 for the padding
+// workgroups of the last round; launch eu_xcd_grid() workgroups.
+__device__ __forceinline__ int eu_xcd_tile(int blk, int tiles_x, int tiles_y, int unit_rows)
 {
   const int nx = 8;
-  int per = nblk / nx, rem = nblk % nx;
-  int xcd = b % nx, k = b / nx;
-  // XCDs [0, rem) own per+1 tiles, the others per tiles
-  return xcd * per + (xcd < rem ? xcd : rem) + k;
+  const int xcd = blk % nx, k = blk / nx;
+  const int unit_tiles = unit_rows * tiles_x;
+  const int ul = k / unit_tiles, iu = k - ul * unit_tiles;
+  const int b = (ul * nx + xcd) * unit_tiles + iu;
+  return b < tiles_x * tiles_y ? b : -1;
 }
+
+static inline int eu_xcd_grid(int tiles_x, int tiles_y, int unit_rows)
+{
+  const int units = (tiles_y + unit_rows - 1) / unit_rows;
+  return ((units + 7) / 8) * 8 * unit_rows * tiles_x;
+}
+
+#define EU_UNIT_ROWS 8
 
 #endif
