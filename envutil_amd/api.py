@@ -151,7 +151,7 @@ class facet_spec:
     (envutil_main.cc:957-960)."""
 
     def __init__(self, projection, width, height, hfov, nchannels=3, yaw=0.0,
-                 pitch=0.0, roll=0.0, brighten=1.0, window=None):
+                 pitch=0.0, roll=0.0, brighten=1.0, window=None, lens=None):
         self.projection = projection
         self.width, self.height = width, height
         self.hfov = hfov
@@ -159,6 +159,7 @@ class facet_spec:
         self.yaw, self.pitch, self.roll = yaw, pitch, roll
         self.brighten = brighten
         self.window = window or (width, height, 0, 0)
+        self.lens = lens or {}          # PTO a, b, c, h, v, g (shear_g), t (shear_t)
 
     def c_struct(self):
         f = Facet()
@@ -170,6 +171,9 @@ class facet_spec:
         f.yaw, f.pitch, f.roll = (math.radians(v) for v in (self.yaw, self.pitch, self.roll))
         f.brighten = self.brighten
         f.step = get_step(self.projection, self.width, self.height, f.hfov)
+        for k, v in self.lens.items():
+            setattr(f, {"g": "shear_g", "t": "shear_t"}.get(k, k), v)
+        f.has_lcp = int(any(self.lens.get(k, 0.0) != 0.0 for k in "abc"))
         return f
 
 

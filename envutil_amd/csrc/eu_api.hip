@@ -113,6 +113,8 @@ void fill_src_dev(eu_source *s)
   d.gate0 = gt[0]; d.gate1 = gt[1];
   d.lower0 = lo[0]; d.upper0 = up[0]; d.lower1 = lo[1]; d.upper1 = up[1];
   d.brighten = (float)f.brighten;
+  d.recip_step = (float)(1.0 / f.step);
+  d.mask_all = is_cube(f.projection) || (f.projection == EU_FISHEYE && f.hfov >= M_PI * 2.0);
   eu::weight_matrix(s->degree, d.wm);
   if (is_cube(f.projection)) return;
   double te[4], we[4];
@@ -126,6 +128,19 @@ void fill_src_dev(eu_source *s)
   px = double(f.window_x_offset + f.window_width) / f.width;
   py = double(f.window_y_offset + f.window_width) / f.width;
   we[1] = te[0] + px * wx; we[3] = te[2] + py * wy;
+  {
+    // process_geometry, envutil_basic.h:499-521; the planar functor is only
+    // installed when the radial polynomial is present (environment.h:1692-1695)
+    double dv = std::fabs(te[3] - te[2]) / 2.0, dh = std::fabs(te[1] - te[0]) / 2.0;
+    d.has_lcp = (f.a != 0.0 || f.b != 0.0 || f.c != 0.0);
+    d.has_shift = d.has_lcp && (f.h != 0.0 || f.v != 0.0);
+    d.has_shear = d.has_lcp && (f.shear_g != 0.0 || f.shear_t != 0.0);
+    d.lens_a = (float)f.a; d.lens_b = (float)f.b; d.lens_c = (float)f.c;
+    d.lens_d = 1.0f - (d.lens_a + d.lens_b + d.lens_c);
+    d.lens_s = (float)((dh < dv) ? dh : dv);
+    d.lens_h = (float)f.h; d.lens_v = (float)f.v;
+    d.shear_g = f.shear_g; d.shear_t = f.shear_t;
+  }
   d.tex_x0 = te[0]; d.tex_y0 = te[2];
   d.ext_w = (float)(te[1] - te[0]); d.ext_h = (float)(te[3] - te[2]);
   d.total_w = (float)f.width; d.total_h = (float)f.height;
@@ -148,10 +163,6 @@ int check_facet(const eu_facet *f)
   if (f->nchannels < 1 || f->nchannels > 4) return fail(EU_ERR_ARGUMENT, "nchannels must be 1..4");
   if (f->projection < 0 || f->projection > EU_BIATAN6) return fail(EU_ERR_ARGUMENT, "unknown source projection");
   if (f->width <= 0 || f->height <= 0) return fail(EU_ERR_ARGUMENT, "empty source image");
-  if (f->projection == EU_FISHEYE)
-    return fail(EU_ERR_UNSUPPORTED, "fisheye sources need libm-exact sinf/cosf on the device: not built yet");
-  if (f->has_lcp)
-    return fail(EU_ERR_UNSUPPORTED, "PTO lens correction (pto_planar) not built yet");
   return EU_OK;
 }
 

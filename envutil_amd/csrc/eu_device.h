@@ -11,12 +11,15 @@
 // ray = f(column table, row table): the steppers' per-segment invariants
 // (stepper.h) hoisted into tables that the host fills once per target.
 enum { EU_FORM_BCA = 0,      // (B*c0 + C*c1) + A   spherical, cylindrical
-       EU_FORM_BA = 1 };     //  B*c0 + A           rectilinear, cubemap, biatan6
+       EU_FORM_BA = 1,       //  B*c0 + A           rectilinear, cubemap, biatan6
+       EU_FORM_FISH = 2 };   //  per-pixel polar form of the fisheye stepper
+                             //  (c0 = planar x, row: xx, yy, zz, planar y)
 enum { EU_NORM_NONE = 0, EU_NORM_DIV = 1, EU_NORM_CYL = 2 };
 
-// number of floats per row-table entry: A, B, C for the unbiased and the
-// y-biased stepper
-#define EU_ROW_FLOATS 18
+// floats per row-table entry: {A, B, C, planar y, pad, pad} for the unbiased
+// and the y-biased stepper
+#define EU_ROW_VARIANT 12
+#define EU_ROW_FLOATS 24
 
 // evaluator + mount parameters of one source, device side
 struct eu_src_dev {
@@ -35,6 +38,12 @@ struct eu_src_dev {
   float win_x_off, win_y_off;
   float wex0, wex1, wex2, wex3;  // window extent narrowed for the compares
   float brighten;
+  // pto_planar (environment.h:240-340), flags as process_geometry sets them
+  int has_lcp, has_shift, has_shear;
+  float lens_a, lens_b, lens_c, lens_d, lens_s, lens_h, lens_v;
+  double shear_g, shear_t;
+  float recip_step;          // float(1.0 / facet.step): z-score weight of the synopsis
+  int mask_all;              // get_mask is constant true (cubemaps, fisheye with hfov >= 2 pi)
   // cubemap_view_t (environment.h:1425-1460)
   float refc_md, model_to_px;
   int section_px;

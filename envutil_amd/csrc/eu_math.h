@@ -123,4 +123,111 @@ EU_HD float eu_atan2f(float y, float x)
   }
 }
 
+// ---------------------------------------------------------------------------
+// sinf / cosf: glibc 2.35 sysdeps/ieee754/flt-32/{s_sinf.c,s_cosf.c,sincosf.h}
+// (the ARM optimized-routines code: double-precision polynomials). On x86_64
+// glibc selects, by ifunc, a variant compiled with -mfma on every CPU that has
+// FMA (sysdeps/x86_64/fpu/multiarch/s_sinf-fma.c); gcc contracts a*b+c there.
+// The contraction pattern below is the one in the image's libm.so.6
+// (__sinf_fma / __cosf_fma, read from its disassembly; constants read from its
+// __sincosf_table and __inv_pio4). Hosts without FMA run a different variant
+// whose results can differ in the last bit: the parity tests run on FMA hosts.
+// ---------------------------------------------------------------------------
+
+#if defined(__HIPCC__) || defined(__FMA__) || defined(EU_MATH_HAVE_FMA)
+#define EU_HAVE_SINCOSF 1
+
+EU_HD double eu_fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// sinf_poly (sincosf.h): n even -> sine polynomial on (x, x2); n odd -> cosine
+// polynomial on x2. neg selects __sincosf_table[1] (negated cosine terms).
+EU_HD float eu_sin_poly(double x, double x2)
+{
+  const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+  double x3 = x * x2;
+  double s1 = eu_fma64(S3, x2, S2);
+  double x7 = x3 * x2;
+  double t = eu_fma64(x3, S1, x);
+  return (float)eu_fma64(s1, x7, t);
+}
+
+EU_HD float eu_cos_poly(double x2, int neg)
+{
+  double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+         C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+  if (neg) { C0 = -C0; C1 = -C1; C2 = -C2; C3 = -C3; C4 = -C4; }
+  double x4 = x2 * x2;
+  double c1 = eu_fma64(C1, x2, C0);
+  double c2 = eu_fma64(C4, x2, C3);
+  double x6 = x4 * x2;
+  double c = eu_fma64(x4, C2, c1);
+  return (float)eu_fma64(c2, x6, c);
+}
+
+// reduce_large (sincosf.h) for |x| >= 120
+EU_HD double eu_reduce_large(uint32_t xi, int *np)
+{
+  const uint32_t inv_pio4[24] = {
+    0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+    0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd,
+    0xf534ddc0, 0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43,
+    0x993c4390, 0x3c439041 };
+  const uint32_t *arr = &inv_pio4[(xi >> 26) & 15];
+  int shift = (xi >> 23) & 7;
+  uint64_t n, res0, res1, res2;
+  xi = (xi & 0xffffff) | 0x800000;
+  xi <<= shift;
+  res0 = (uint32_t)(xi * arr[0]);
+  res1 = (uint64_t)xi * arr[4];
+  res2 = (uint64_t)xi * arr[8];
+  res0 = (res2 >> 32) | (res0 << 32);
+  res0 += res1;
+  n = (res0 + (1ULL << 61)) >> 62;
+  res0 -= n << 62;
+  double x = (double)(int64_t)res0;
+  *np = (int)n;
+  return x * 0x1.921fb54442d18p-62;
+}
+
+// which = 0: sinf, 1: cosf
+EU_HD float eu_sincosf_impl(float y, int which)
+{
+  const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
+  double x = (double)y;
+  uint32_t top = (eu_f2u(y) >> 20) & 0x7ff;
+  if (top <= 0x3f3) {                  // |y| < pi/4
+    double x2 = x * x;
+    if (top <= 0x397) return which ? 1.0f : y;     // |y| < 2^-12
+    return which ? eu_cos_poly(x2, 0) : eu_sin_poly(x, x2);
+  }
+  int n;
+  double xr;
+  int sign = 0;
+  if (top <= 0x42e) {                  // |y| < 120: reduce_fast
+    double r = x * hpi_inv;
+    n = ((int32_t)r + 0x800000) >> 24;
+    xr = eu_fma64(-(double)n, hpi, x);
+  } else if (top <= 0x7f7) {
+    uint32_t xi = eu_f2u(y);
+    sign = (int)(xi >> 31);
+    xr = eu_reduce_large(xi, &n);
+  } else {
+    return (y - y) / (y - y);          // __math_invalidf: NaN
+  }
+  // sin: s = sign[(n + sign) & 3], table by (n + sign) & 2, polynomial by n
+  // cos: s = sign[(n + sign) & 3], table by (n + sign) & 2, polynomial by n ^ 1
+  // (for |y| < 120 sign = 0: reduce_fast keeps the sign in x)
+  int ns = n + sign;
+  double s = ((ns & 3) == 1 || (ns & 3) == 2) ? -1.0 : 1.0;
+  int neg = (ns & 2) != 0;
+  int odd = (n ^ which) & 1;
+  double x2 = xr * xr;
+  if (!odd) return eu_sin_poly(xr * s, x2);
+  return eu_cos_poly(x2, neg);
+}
+
+EU_HD float eu_sinf(float y) { return eu_sincosf_impl(y, 0); }
+EU_HD float eu_cosf(float y) { return eu_sincosf_impl(y, 1); }
+#endif
+
 #endif

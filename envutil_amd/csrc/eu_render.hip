@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
     const float *col2 = p.col + 2 * p.width, *col3 = p.col + 3 * p.width;
     float ax, ay, az, bx, by, bz;
     eu_stepper(p, col2, col3, rowt, x, ax, ay, az);          // r10: x-biased
-    eu_stepper(p, col0, col1, rowt + 9, x, bx, by, bz);      // r01: y-biased
+    eu_stepper(p, col0, col1, rowt + EU_ROW_VARIANT, x, bx, by, bz);      // r01: y-biased
     float dxx = ax - rx, dxy = ay - ry, dxz = az - rz;
     float dyx = bx - rx, dyy = by - ry, dyz = bz - rz;
 #pragma unroll

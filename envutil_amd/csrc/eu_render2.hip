@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params 
     // deriv_stepper (stepper.h:1591-1715) + twine_t::eval (twining.h:128-263)
     const eu_ray2 r10 = eu_rays2(p.form, p.norm_mode, rowt, p.col + 2 * p.width,
                                  p.col + 3 * p.width, xa, xbc);
-    const eu_ray2 r01 = eu_rays2(p.form, p.norm_mode, rowt + 9, p.col, p.col + p.width, xa, xbc);
+    const eu_ray2 r01 = eu_rays2(p.form, p.norm_mode, rowt + EU_ROW_VARIANT, p.col, p.col + p.width, xa, xbc);
     const eu_f2 dxx = r10.x - r00.x, dxy = r10.y - r00.y, dxz = r10.z - r00.z;
     const eu_f2 dyx = r01.x - r00.x, dyy = r01.y - r00.y, dyz = r01.z - r00.z;
 #pragma unroll
@@ -409,7 +409,7 @@ static int launch2_n(const eu_render_params &p, hipStream_t st)
 extern "C" int eu_launch_render2(const eu_render_params *pp, void *stream)
 {
   eu_render_params p = *pp;
-  if (p.stage != 0) return 1;
+  if (p.stage != 0 || p.form == EU_FORM_FISH || p.src.has_lcp) return 1;
   if (p.src.prj != EU_SPHERICAL && p.src.prj != EU_CUBEMAP && p.src.prj != EU_BIATAN6) return 1;
   if (p.src.degree < 1 || p.src.degree > 3 || p.src.es0 != p.nch) return 1;
   static const int unit_rows = [] { const char *e = getenv("EU_HIP_UNIT"); return e ? atoi(e) : EU2_UNIT_ROWS; }();

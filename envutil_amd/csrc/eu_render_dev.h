@@ -305,10 +305,37 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
       c1 = d * factor;
       break;
     }
-    default:
-      // fisheye sources need sinf/cosf with libm's bits: next row of the plan
-      c0 = 0.0f; c1 = 0.0f;
+    default: {                 // ray_to_fish_t, geometry.h:513-531
+      float q = sqrtf(rx * rx + ry * ry);
+      float r = (float)1.57079632679489661923 - eu_atan2f(rz, q);
+      float phi = eu_atan2f(ry, rx);
+      c0 = r * eu_cosf(phi);
+      c1 = r * eu_sinf(phi);
       break;
+    }
+  }
+  if (s.has_lcp) {
+    // pto_planar, forward direction (environment.h:254-284): radial polynomial
+    // (lens_correction.h:93-105), shift, shear
+    float o0 = c0, o1 = c1;
+    {
+      float sqn = c0 * c0;
+      sqn = sqn + c1 * c1;
+      float x = sqrtf(sqn) / s.lens_s;
+      float sum = 0.0f, power = 1.0f;
+      sum = sum + s.lens_d * power; power = power * x;
+      sum = sum + s.lens_c * power; power = power * x;
+      sum = sum + s.lens_b * power; power = power * x;
+      sum = sum + s.lens_a * power;
+      o0 = o0 * sum; o1 = o1 * sum;
+    }
+    if (s.has_shift) { o0 = o0 + s.lens_h; o1 = o1 + s.lens_v; }
+    if (s.has_shear) {
+      float h0 = (float)((double)o0 + ((double)o1 * s.shear_g));
+      float h1 = (float)((double)o1 + ((double)o0 * s.shear_t));
+      o0 = h0; o1 = h1;
+    }
+    c0 = o0; c1 = o1;
   }
   // source_t::test_crd, environment.h:970-977 (float compares)
   bool mask = c0 >= s.wex0 && c0 <= s.wex1 && c1 >= s.wex2 && c1 <= s.wex3;
@@ -358,7 +385,21 @@ __device__ __forceinline__ void eu_ray(int form, const float *rowt, float c0, fl
                                        float &rx, float &ry, float &rz)
 {
   // rowt: A[3], B[3], C[3]
-  if (form == EU_FORM_BCA) {
+  if (form == EU_FORM_FISH) {
+    // fisheye_stepper::work, stepper.h:1019-1030: a = M_PI_2 - norm(planar) is
+    // formed in double and narrows to float before sin/cos (the float sincos
+    // overload is the one that binds)
+    const float p0 = c0, p1 = rowt[9];
+    float sqn = p0 * p0;
+    sqn = sqn + p1 * p1;
+    const float nrm = sqrtf(sqn);
+    const float a = (float)(1.57079632679489661923 - (double)nrm);
+    const float bb = eu_atan2f(p0, p1);
+    const float z = eu_sinf(a), r = eu_cosf(a), sx = eu_sinf(bb), sy = eu_cosf(bb);
+    rx = rowt[0] * r * sx + rowt[6] * z + rowt[3] * r * sy;
+    ry = rowt[1] * r * sx + rowt[7] * z + rowt[4] * r * sy;
+    rz = rowt[2] * r * sx + rowt[8] * z + rowt[5] * r * sy;
+  } else if (form == EU_FORM_BCA) {
     rx = rowt[3] * c0 + rowt[6] * c1 + rowt[0];
     ry = rowt[4] * c0 + rowt[7] * c1 + rowt[1];
     rz = rowt[5] * c0 + rowt[8] * c1 + rowt[2];

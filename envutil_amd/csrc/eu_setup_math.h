@@ -407,13 +407,23 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
         if (twine) tb.col[(size_t)2 * W + x] = std::tan(p0b[x] * q);
       }
       break;
+    case EU_FISHEYE:
+      // fisheye_stepper::work (stepper.h:1019-1030) has no per-row or per-column
+      // invariant beyond the planar coordinates themselves
+      tb.form = EU_FORM_FISH;
+      for (int x = 0; x < W; x++) {
+        tb.col[x] = p0[x];
+        if (twine) tb.col[(size_t)2 * W + x] = p0b[x];
+      }
+      break;
     default:
-      return false;
+      return false;   // stereographic: needs libm's double atan on the device
   }
   for (int y = 0; y < H; y++) {
     for (int v = 0; v < (twine ? 2 : 1); v++) {
       float p1 = planar_row(H, b0, b1, v ? 0.25f : 0.0f, y);
-      float *r = &tb.row[(size_t)y * EU_ROW_FLOATS + 9 * v];   // A, B, C
+      float *r = &tb.row[(size_t)y * EU_ROW_FLOATS + EU_ROW_VARIANT * v];   // A, B, C, planar y
+      r[9] = p1;
       switch (prj) {
         case EU_SPHERICAL: {     // stepper.h:605-667
           float sy = std::sin(p1), rr = std::cos(p1);
@@ -425,6 +435,9 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
           break;
         case EU_RECTILINEAR:     // stepper.h:895-932
           for (int i = 0; i < 3; i++) { r[3 + i] = xx[i]; r[i] = yy[i] * p1 + zz[i]; }
+          break;
+        case EU_FISHEYE:
+          for (int i = 0; i < 3; i++) { r[i] = xx[i]; r[3 + i] = yy[i]; r[6 + i] = zz[i]; }
           break;
         default: {               // cubemap, biatan6: stepper.h:1274-1358, :1449-1560
           int face = y / W;

@@ -1252,6 +1252,7 @@ static void ray_to_planar(int projection, const float *ray, float *crd)
 
 /* pto_planar forward direction, environment.h:240-340 + lens_correction.h */
 static void planar_lens(const euo_source *src, float *crd);
+static int mount_mask(const mount_t *m, const float *ray);
 
 /* returns the hit mask; px gets nch floats */
 static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
@@ -1317,11 +1318,55 @@ static void brighten_px(const mount_t *m, float *px)
 }
 
 /* lens polynomial + shift + shear, PTO forward direction
- * (environment.h:254-284; lens_correction.h:93-105, :224-235) */
+ * (environment.h:254-284; lens_correction.h:93-105, :224-235). The flags and
+ * the scale s come from process_geometry (envutil_basic.h:499-521). */
 static void planar_lens(const euo_source *src, float *crd)
 {
-  /* restated when configuration 5 (multi-facet PTO) is built */
-  (void)src; (void)crd;
+  double ext[4];
+  euo_get_extent(src->projection, src->width, src->height, src->hfov, ext);
+  double dv = fabs(ext[3] - ext[2]) / 2.0, dh = fabs(ext[1] - ext[0]) / 2.0;
+  double sd = (dh < dv) ? dh : dv;
+  int has_lcp = (src->a != 0.0 || src->b != 0.0 || src->c != 0.0);
+  int has_shift = (src->h != 0.0 || src->v != 0.0);
+  int has_shear = (src->shear_g != 0.0 || src->shear_t != 0.0);
+  float o0 = crd[0], o1 = crd[1];
+  if (has_lcp) {
+    /* lcp<float>: coefficients {a, b, c, 1 - (a + b + c)} in float */
+    float a = (float)src->a, b = (float)src->b, c = (float)src->c;
+    float d = 1.0f - (a + b + c);
+    float sqn = crd[0] * crd[0];
+    sqn += crd[1] * crd[1];
+    float x = sqrtf(sqn) / (float)sd;
+    float sum = 0.0f, power = 1.0f;
+    sum += d * power; power *= x;
+    sum += c * power; power *= x;
+    sum += b * power; power *= x;
+    sum += a * power; power *= x;
+    o0 *= sum; o1 *= sum;
+  }
+  if (has_shift) { o0 += (float)src->h; o1 += (float)src->v; }
+  if (has_shear) {
+    /* vec<float> * double -> double (A.0) */
+    float h0 = (float)((double)o0 + ((double)o1 * src->shear_g));
+    float h1 = (float)((double)o1 + ((double)o0 * src->shear_t));
+    o0 = h0; o1 = h1;
+  }
+  crd[0] = o0; crd[1] = o1;
+}
+
+/* mount_t::get_mask (environment.h:1151-1159): does the ray hit the facet? */
+static int mount_mask(const mount_t *m, const float *ray)
+{
+  const euo_source *src = m->src;
+  if (src->projection == EUO_CUBEMAP || src->projection == EUO_BIATAN6) return 1;
+  if (src->projection == EUO_FISHEYE && src->hfov >= M_PI * 2.0) return 1;   /* environment.h:1747-1749 */
+  float crd[2] = { 0.0f, 0.0f };
+  ray_to_planar(src->projection, ray, crd);
+  if (src->has_lcp) planar_lens(src, crd);
+  int mask = crd[0] >= m->wexf[0] && crd[0] <= m->wexf[1]
+          && crd[1] >= m->wexf[2] && crd[1] <= m->wexf[3];
+  if (src->projection == EUO_RECTILINEAR) mask = mask && (ray[2] > 0.0f);
+  return mask;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1330,10 +1375,201 @@ static void planar_lens(const euo_source *src, float *crd)
 /*  twining.h:128-263)                                                       */
 /* ------------------------------------------------------------------------ */
 
+/* ------------------------------------------------------------------------ */
+/* multi-facet rendering: fusion_t (zimt/get.h:1181-1242) + synopsis          */
+/* (envutil_payload.cc:587-691 synopsis_t, :762-957 _voronoi_syn,             */
+/*  :964-1233 _voronoi_syn_plus). The synopsis objects take some decisions per */
+/* 16-lane VECTOR (any_of / all_of); the oracle therefore works on groups of   */
+/* EUO_LANES pixels that start at segment boundaries, like zimt::process.      */
+/* ------------------------------------------------------------------------ */
+
+#define EUO_MAX_FACETS 64
+
+typedef struct {
+  int nfct, nch, plus;
+  mount_t mnt[EUO_MAX_FACETS];
+  float recip_step[EUO_MAX_FACETS];
+} syn_t;
+
+/* rays[f][lane][3] -> px[lane][nch] for n valid lanes */
+static void synopsis_group(const syn_t *sy, float rays[][EUO_LANES][3], int n, float px[][4])
+{
+  int nf = sy->nfct, nch = sy->nch;
+  if (!sy->plus) {
+    /* _voronoi_syn: champion = facet with the largest z * recip_step among the
+     * facets the ray hits; strict '>' keeps the earlier facet on ties */
+    for (int l = 0; l < n; l++) {
+      int champ = -1;
+      float max_z = -FLT_MAX;
+      for (int f = 0; f < nf; f++) {
+        if (!mount_mask(&sy->mnt[f], rays[f][l])) continue;
+        float z = rays[f][l][2] * sy->recip_step[f];
+        if (champ == -1 && f == 0) { champ = 0; max_z = z; continue; }
+        float cur = z;
+        if (cur > max_z) { max_z = cur; champ = f; }
+      }
+      for (int c = 0; c < nch; c++) px[l][c] = 0.0f;
+      if (champ >= 0) {
+        mount_eval(&sy->mnt[champ], rays[champ][l], px[l], NULL);
+        brighten_px(&sy->mnt[champ], px[l]);
+      }
+    }
+    return;
+  }
+  /* _voronoi_syn_plus: per lane a list of (z, facet) sorted by z, one slot per
+   * facet that is valid for ANY lane of the vector */
+  static _Thread_local float maxz[EUO_MAX_FACETS][EUO_LANES];
+  static _Thread_local int champ[EUO_MAX_FACETS][EUO_LANES];
+  static _Thread_local float lv[EUO_MAX_FACETS][EUO_LANES][4];
+  int layers = 0, next_best = -1;
+  for (int f = 0; f < nf; f++) {
+    int valid[EUO_LANES], any = 0;
+    for (int l = 0; l < n; l++) { valid[l] = mount_mask(&sy->mnt[f], rays[f][l]); any |= valid[l]; }
+    if (f == 0) {
+      for (int l = 0; l < n; l++) { maxz[0][l] = -FLT_MAX; champ[0][l] = -1; }
+      if (any) {
+        next_best = 0; layers = 1;
+        for (int l = 0; l < n; l++) if (valid[l]) { champ[0][l] = 0; maxz[0][l] = rays[0][l][2] * sy->recip_step[0]; }
+      }
+      continue;
+    }
+    if (!any) continue;
+    next_best = f;
+    for (int l = 0; l < n; l++) {
+      maxz[layers][l] = valid[l] ? rays[f][l][2] * sy->recip_step[f] : -FLT_MAX;
+      champ[layers][l] = valid[l] ? f : -1;
+    }
+    for (int k = layers; k > 0; --k) {
+      int swapped = 0;
+      for (int l = 0; l < n; l++)
+        if (maxz[k][l] > maxz[k - 1][l]) {
+          float tz = maxz[k][l]; maxz[k][l] = maxz[k - 1][l]; maxz[k - 1][l] = tz;
+          int tc = champ[k][l]; champ[k][l] = champ[k - 1][l]; champ[k - 1][l] = tc;
+          swapped = 1;
+        }
+      if (!swapped) break;
+    }
+    ++layers;
+  }
+  for (int l = 0; l < n; l++) for (int c = 0; c < nch; c++) px[l][c] = 0.0f;
+  if (layers == 0) return;
+  int all_top = 1;
+  for (int l = 0; l < n; l++) if (champ[0][l] != next_best) all_top = 0;
+  if (all_top) {
+    /* one facet on top everywhere and fully opaque: take it as is */
+    float help[EUO_LANES][4];
+    int opaque = 1;
+    for (int l = 0; l < n; l++) {
+      mount_eval(&sy->mnt[next_best], rays[next_best][l], help[l], NULL);
+      brighten_px(&sy->mnt[next_best], help[l]);
+      if (!(help[l][nch - 1] >= 1.0f)) opaque = 0;
+    }
+    if (opaque) {
+      for (int l = 0; l < n; l++) for (int c = 0; c < nch; c++) px[l][c] = help[l][c];
+      return;
+    }
+  }
+  for (int f = 0; f < nf; f++)
+    for (int l = 0; l < n; l++) {
+      mount_eval(&sy->mnt[f], rays[f][l], lv[f][l], NULL);
+      brighten_px(&sy->mnt[f], lv[f][l]);
+    }
+  for (int i = 0; i < layers; i++)
+    for (int l = 0; l < n; l++) {
+      int ci = champ[i][l];
+      if (ci == -1) continue;
+      const float *help = lv[ci][l];
+      if (i == 0) for (int c = 0; c < nch; c++) px[l][c] = help[c];
+      else for (int c = 0; c < nch; c++) px[l][c] += (1.0f - px[l][nch - 1]) * help[c];
+    }
+}
+
+static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc,
+                            float *out, long ors)
+{
+  int nch = job->nch, W = job->width;
+  if (nsrc > EUO_MAX_FACETS) return -2;
+  syn_t *sy = (syn_t *)calloc(1, sizeof(syn_t));
+  stepper_t *st = (stepper_t *)calloc(3 * (size_t)nsrc, sizeof(stepper_t));
+  sy->nfct = nsrc; sy->nch = nch; sy->plus = (nch == 2 || nch == 4);
+  double r_cam[9];
+  euo_make_r3(job->roll, job->pitch, job->yaw, 0, r_cam);
+  for (int f = 0; f < nsrc; f++) {
+    if (srcs[f].spl.nch != nch) { free(sy); free(st); return -3; }
+    double r_fct[9], basis[9];
+    euo_make_r3(srcs[f].roll, srcs[f].pitch, srcs[f].yaw, 1, r_fct);
+    euo_rotate_r3(r_cam, r_fct, basis);
+    /* multi-facet steppers are built with normalize = true (payload.cc:2152) */
+    stepper_init(&st[3 * f], job->projection, 1, basis, W, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.0f);
+    stepper_init(&st[3 * f + 1], job->projection, 1, basis, W, job->height, job->x0, job->x1, job->y0, job->y1, 0.25f, 0.0f);
+    stepper_init(&st[3 * f + 2], job->projection, 1, basis, W, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.25f);
+    mount_init(&sy->mnt[f], &srcs[f]);
+    sy->recip_step[f] = (float)(1.0 / srcs[f].step);
+  }
+  int twining = job->ntaps > 0;
+  float *taps = NULL;
+  if (twining) {
+    taps = (float *)malloc(sizeof(float) * 3 * (size_t)job->ntaps);
+    for (int k = 0; k < job->ntaps; k++) {
+      taps[3 * k] = job->taps[3 * k] * 4.0f;
+      taps[3 * k + 1] = job->taps[3 * k + 1] * 4.0f;
+      taps[3 * k + 2] = job->taps[3 * k + 2];
+    }
+  }
+  int nthreads = job->nthreads > 0 ? job->nthreads : 1;
+#pragma omp parallel for schedule(dynamic, 2) num_threads(nthreads)
+  for (int y = job->row_begin; y < job->row_end; y++) {
+    float *row = out + (long)(y - job->row_begin) * ors;
+    float (*rays)[EUO_LANES][3] = malloc(sizeof(float) * (size_t)nsrc * EUO_LANES * 3);
+    float (*p0)[EUO_LANES][3] = malloc(sizeof(float) * (size_t)nsrc * EUO_LANES * 3);
+    float (*du)[EUO_LANES][3] = malloc(sizeof(float) * (size_t)nsrc * EUO_LANES * 3);
+    float (*dv)[EUO_LANES][3] = malloc(sizeof(float) * (size_t)nsrc * EUO_LANES * 3);
+    for (int seg = 0; seg < W; seg += EUO_SEGMENT)
+      for (int x0 = seg; x0 < W && x0 < seg + EUO_SEGMENT; x0 += EUO_LANES) {
+        int n = W - x0 < EUO_LANES ? W - x0 : EUO_LANES;
+        float px[EUO_LANES][4];
+        if (!twining) {
+          for (int f = 0; f < nsrc; f++)
+            for (int l = 0; l < n; l++) stepper_ray(&st[3 * f], x0 + l, y, rays[f][l]);
+          synopsis_group(sy, rays, n, px);
+        } else {
+          /* synopsis_t::operator() for ninepacks (payload.cc:647-690) */
+          for (int f = 0; f < nsrc; f++)
+            for (int l = 0; l < n; l++) {
+              float r10[3], r01[3];
+              stepper_ray(&st[3 * f], x0 + l, y, p0[f][l]);
+              stepper_ray(&st[3 * f + 1], x0 + l, y, r10);
+              stepper_ray(&st[3 * f + 2], x0 + l, y, r01);
+              for (int i = 0; i < 3; i++) { du[f][l][i] = r10[i] - p0[f][l][i]; dv[f][l][i] = r01[i] - p0[f][l][i]; }
+            }
+          float acc[EUO_LANES][4];
+          memset(acc, 0, sizeof acc);
+          for (int k = 0; k < job->ntaps; k++) {
+            for (int f = 0; f < nsrc; f++)
+              for (int l = 0; l < n; l++)
+                for (int i = 0; i < 3; i++)
+                  rays[f][l][i] = p0[f][l][i] + taps[3 * k] * du[f][l][i] + taps[3 * k + 1] * dv[f][l][i];
+            float help[EUO_LANES][4];
+            synopsis_group(sy, rays, n, help);
+            for (int l = 0; l < n; l++)
+              for (int c = 0; c < nch; c++) acc[l][c] += taps[3 * k + 2] * help[l][c];
+          }
+          memcpy(px, acc, sizeof acc);
+        }
+        for (int l = 0; l < n; l++)
+          for (int c = 0; c < nch; c++) row[(long)(x0 + l) * nch + c] = px[l][c];
+      }
+    free(rays); free(p0); free(du); free(dv);
+  }
+  free(taps); free(sy); free(st);
+  return 0;
+}
+
 int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
                float *out, long ors)
 {
-  if (nsrc != 1) return -2;     /* multi-facet synopsis: next row */
+  if (nsrc > 1) return euo_render_multi(job, srcs, nsrc, out, ors);
+  if (nsrc != 1) return -2;
   const euo_source *src = &srcs[0];
   int nch = job->nch;
   if (src->spl.nch != nch) return -3;

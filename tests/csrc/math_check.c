@@ -79,3 +79,29 @@ long check_atan2f_pairs(const float *y, const float *x, long n)
     if (!same(eu_atan2f(y[i], x[i]), atan2f(y[i], x[i]))) bad++;
   return bad;
 }
+
+#ifdef EU_HAVE_SINCOSF
+/* every float bit pattern in [first, last]: which = 0 sinf, 1 cosf */
+long check_sincosf_range(uint32_t first, uint32_t last, int which, uint32_t *first_bad)
+{
+  long bad = 0;
+  uint32_t fb = 0;
+#pragma omp parallel for reduction(+:bad) schedule(static)
+  for (long long u = first; u <= (long long)last; u++) {
+    float x;
+    uint32_t uu = (uint32_t)u;
+    memcpy(&x, &uu, 4);
+    float a = which ? eu_cosf(x) : eu_sinf(x), b = which ? cosf(x) : sinf(x);
+    if (!same(a, b)) {
+      bad++;
+#pragma omp critical
+      if (!fb) fb = uu;
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return bad;
+}
+int have_sincosf(void) { return 1; }
+#else
+int have_sincosf(void) { return 0; }
+#endif

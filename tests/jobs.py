@@ -45,7 +45,7 @@ class OracleSource:
 
     def __init__(self, prj, width, height, hfov_deg, pixels, spline_degree,
                  prefilter_degree=None, yaw=0.0, pitch=0.0, roll=0.0, brighten=1.0,
-                 support_min=8, tile=64):
+                 support_min=8, tile=64, lens=None):
         if prefilter_degree is None:
             prefilter_degree = spline_degree
         hf = math.radians(hfov_deg)
@@ -59,6 +59,11 @@ class OracleSource:
         s.yaw, s.pitch, s.roll = (math.radians(v) for v in (yaw, pitch, roll))
         s.brighten = brighten
         s.step = euo.lib().euo_get_step(prj, width, height, hf)
+        if lens:
+            # PTO lens parameters a, b, c (radial), h, v (shift), g, t (shear)
+            for k, v in lens.items():
+                setattr(s, {"g": "shear_g", "t": "shear_t"}.get(k, k), v)
+            s.has_lcp = int(any(lens.get(k, 0.0) != 0.0 for k in "abc"))
         if prj in (euo.CUBEMAP, euo.BIATAN6):
             m, ir = euo.cubemap_build(pixels, spline_degree, prefilter_degree, hf,
                                       support_min, tile)

@@ -35,7 +35,8 @@ def make_pair(prj, w, h, hfov, img, degree, pdeg=None, **kw):
     o = jobs.OracleSource(prj, w, h, hfov, img, degree, pdeg, **kw)
     fct = ea.facet_spec(prj, w, h, hfov, nchannels=img.shape[2],
                         yaw=kw.get("yaw", 0.0), pitch=kw.get("pitch", 0.0),
-                        roll=kw.get("roll", 0.0), brighten=kw.get("brighten", 1.0))
+                        roll=kw.get("roll", 0.0), brighten=kw.get("brighten", 1.0),
+                        lens=kw.get("lens"))
     # the GPU gets the oracle's coefficients: stage-wise parity of the render
     # path alone ("given identical coefficients")
     g = ea.Source.adopt(fct, o.container, degree, o.bc[0], o.bc[1])
@@ -49,6 +50,7 @@ TARGETS = [
     (ea.CYLINDRICAL, 150, 70, 220.0),
     (ea.BIATAN6, 24, 144, 90.0),
     (ea.SPHERICAL, 1100, 12, 360.0),      # segments of 512 + leftover lanes
+    (ea.FISHEYE, 120, 90, 200.0),         # per-pixel sinf/cosf/atan2f on the device
 ]
 
 
@@ -86,15 +88,18 @@ def test_pixels_bit_exact_latlon_source(latlon, degree, nch):
     (euo.CYLINDRICAL, 256, 100, 360.0),
     (euo.SPHERICAL, 200, 80, 220.0),        # partial sphere: REFLECT, ordinary prefilter
     (euo.STEREOGRAPHIC, 160, 160, 150.0),
+    (euo.FISHEYE, 180, 180, 190.0),
 ])
-def test_pixels_bit_exact_other_mounts(sprj, sw, sh, shfov):
+@pytest.mark.parametrize("lens", [None, dict(a=0.01, b=-0.03, c=0.02),
+                                  dict(a=0.02, b=0.0, c=-0.01, h=0.01, v=-0.02, g=0.003, t=-0.002)])
+def test_pixels_bit_exact_other_mounts(sprj, sw, sh, shfov, lens):
     img = jobs.synth_image(sw, sh, 3, seed=99)
-    o, g = make_pair(sprj, sw, sh, shfov, img, 3, yaw=10, pitch=5, roll=-3, brighten=1.25)
+    o, g = make_pair(sprj, sw, sh, shfov, img, 3, yaw=10, pitch=5, roll=-3, brighten=1.25, lens=lens)
     for tprj, tw, th, thfov in [(ea.SPHERICAL, 160, 80, 360.0), (ea.RECTILINEAR, 100, 80, 70.0)]:
         a = ea.arguments(tprj, tw, th, thfov, yaw=5, pitch=2, roll=1, spline_degree=3)
         got, ref = ea.render(a, g), jobs.oracle_render(a, o)
         assert_bits(got, ref, f"mount {sprj}")
-        if tprj == ea.SPHERICAL and sprj != euo.CYLINDRICAL:
+        if tprj == ea.SPHERICAL and sprj not in (euo.CYLINDRICAL, euo.FISHEYE):
             # the source does not cover the sphere: the miss path was exercised
             assert (ref == 0).all(axis=2).any() and (ref != 0).any()
 
