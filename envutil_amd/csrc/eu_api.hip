@@ -15,6 +15,7 @@
 
 extern "C" int eu_launch_render(const eu_render_params *p, void *stream);
 extern "C" int eu_launch_diag(const eu_render_params *p, unsigned long long *stamps_dev, void *stream);
+extern "C" int eu_launch_render_multi(const void *p, int degree, void *stream);
 extern "C" int eu_launch_render2(const eu_render_params *p, void *stream);
 extern "C" int eu_verify_const_div(float c, float limit, void *stream);
 extern "C" int eu_launch_selftest(unsigned long long seed, int blocks, int iters,
@@ -54,6 +55,12 @@ struct context {
   // target many times (envutil_main.cc:1948-1982)
   std::vector<unsigned char> plan_key;
   int plan_form = 0, plan_norm = 0;
+  // multi-facet jobs keep their own tables
+  float *mcol = nullptr, *mrow = nullptr, *mtaps = nullptr;
+  size_t mcol_cap = 0, mrow_cap = 0, mtaps_cap = 0;
+  eu_src_dev *msrc = nullptr; size_t msrc_cap = 0;
+  std::vector<unsigned char> mplan_key;
+  int mplan_form = 0, mplan_norm = 0;
 } g;
 
 #define HIPCHK(call)                                                          \
@@ -284,6 +291,92 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   return EU_OK;
 }
 
+// mirror of eu_multi_params (eu_render_multi.hip)
+struct multi_params {
+  int width, height, row_begin, row_end;
+  int form, norm_mode, twine, ntaps, nch, nfct, plus;
+  const float *col, *row, *taps;
+  const eu_src_dev *srcs;
+  float *out;
+  long long out_stride;
+  int tiles_x, tiles_y;
+};
+
+// fuse() for several facets (envutil_payload.cc:2139-2180, :2240-2281): one
+// stepper per facet, all with normalize = true, synopsis by channel count
+int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out_dev,
+                size_t row_stride_bytes, multi_params *p, int *degree)
+{
+  if (nsrc > 16) return fail(EU_ERR_UNSUPPORTED, "more than 16 facets per job not built yet");
+  const eu_source *s0 = srcs[0];
+  for (int f = 0; f < nsrc; f++) {
+    if (!srcs[f]) return fail(EU_ERR_HANDLE, "null source");
+    if (srcs[f]->nch != t->nchannels)
+      return fail(EU_ERR_UNSUPPORTED, "channel adaption (repix_t) not built yet: target and source channel counts differ");
+    if (srcs[f]->degree != s0->degree) return fail(EU_ERR_ARGUMENT, "facets must share the spline degree");
+  }
+  const bool twine = t->ntaps > 0;
+  std::vector<unsigned char> key(sizeof(eu_target) + (size_t)nsrc * 3 * sizeof(double)
+                                 + 3 * sizeof(float) * (size_t)t->ntaps + sizeof(int));
+  {
+    eu_target tk = *t;
+    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0;
+    unsigned char *q = key.data();
+    memcpy(q, &tk, sizeof tk); q += sizeof tk;
+    memcpy(q, &nsrc, sizeof(int)); q += sizeof(int);
+    for (int f = 0; f < nsrc; f++) {
+      double fo[3] = { srcs[f]->fct.yaw, srcs[f]->fct.pitch, srcs[f]->fct.roll };
+      memcpy(q, fo, sizeof fo); q += sizeof fo;
+    }
+    if (twine) memcpy(q, t->taps, 3 * sizeof(float) * (size_t)t->ntaps);
+  }
+  int rc;
+  if (key != g.mplan_key) {
+    eu::mat3 r_cam = eu::make_r3(t->roll, t->pitch, t->yaw, false);
+    std::vector<float> rows;
+    eu::stepper_tables tb;
+    for (int f = 0; f < nsrc; f++) {
+      eu::mat3 r_fct = eu::make_r3(srcs[f]->fct.roll, srcs[f]->fct.pitch, srcs[f]->fct.yaw, true);
+      eu::mat3 basis = eu::rotate(r_cam, r_fct);
+      if (!eu::build_stepper_tables(*t, basis, true, twine, tb))
+        return fail(EU_ERR_UNSUPPORTED, "stereographic target stepper not built yet");
+      rows.insert(rows.end(), tb.row.begin(), tb.row.end());
+    }
+    if ((rc = grow(&g.mcol, &g.mcol_cap, tb.col.size()))) return rc;
+    if ((rc = grow(&g.mrow, &g.mrow_cap, rows.size()))) return rc;
+    HIPCHK(hipMemcpyAsync(g.mcol, tb.col.data(), tb.col.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.mrow, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    std::vector<float> taps;
+    if (twine) {
+      taps.assign(t->taps, t->taps + 3 * (size_t)t->ntaps);
+      for (int k = 0; k < t->ntaps; k++) { taps[3 * k] *= 4.0f; taps[3 * k + 1] *= 4.0f; }
+      if ((rc = grow(&g.mtaps, &g.mtaps_cap, taps.size()))) return rc;
+      HIPCHK(hipMemcpyAsync(g.mtaps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.mplan_form = tb.form; g.mplan_norm = tb.norm_mode;
+    g.mplan_key.swap(key);
+  }
+  // the facets' evaluator parameters (they can change between jobs: always refreshed)
+  std::vector<eu_src_dev> sd((size_t)nsrc);
+  for (int f = 0; f < nsrc; f++) sd[f] = srcs[f]->sd;
+  if (g.msrc_cap < (size_t)nsrc) {
+    if (g.msrc) (void)hipFree(g.msrc);
+    HIPCHK(hipMalloc((void **)&g.msrc, sizeof(eu_src_dev) * (size_t)nsrc));
+    g.msrc_cap = (size_t)nsrc;
+  }
+  HIPCHK(hipMemcpyAsync(g.msrc, sd.data(), sizeof(eu_src_dev) * (size_t)nsrc, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  memset(p, 0, sizeof *p);
+  p->width = t->width; p->height = t->height; p->row_begin = t->row_begin; p->row_end = t->row_end;
+  p->form = g.mplan_form; p->norm_mode = g.mplan_norm; p->twine = twine; p->ntaps = t->ntaps;
+  p->nch = t->nchannels; p->nfct = nsrc; p->plus = (t->nchannels == 2 || t->nchannels == 4);
+  p->col = g.mcol; p->row = g.mrow; p->taps = g.mtaps; p->srcs = g.msrc;
+  p->out = out_dev; p->out_stride = (long long)(row_stride_bytes / sizeof(float));
+  *degree = s0->degree;
+  return EU_OK;
+}
+
 // the packed two-pixel kernel where it applies, the general kernel otherwise
 // (EU_HIP_KERNEL=1 forces the general kernel: A/B switch)
 int launch_render(const eu_render_params *p, void *st)
@@ -487,8 +580,20 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   const size_t min_stride = (size_t)trg->width * och * sizeof(float);
   if (out_row_stride_bytes < min_stride) return fail(EU_ERR_ARGUMENT, "row stride smaller than a row");
   eu_render_params p;
+  multi_params mp;
+  int mdeg = 0;
   hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+  if (!srcs || nsrc < 1) return fail(EU_ERR_ARGUMENT, "no source");
+  if (trg->row_begin < 0 || trg->row_end > trg->height || trg->row_begin > trg->row_end)
+    return fail(EU_ERR_ARGUMENT, "row range outside the target");
+  const bool multi = nsrc > 1;
+  if (multi && trg->stage) return fail(EU_ERR_ARGUMENT, "stage outputs exist for single-facet jobs only");
   if (out_on_device) {
+    if (multi) {
+      if ((rc = build_multi(trg, srcs, nsrc, out, out_row_stride_bytes, &mp, &mdeg))) return rc;
+      if (eu_launch_render_multi(&mp, mdeg, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+      return EU_OK;
+    }
     if ((rc = build_params(trg, srcs, nsrc, out, out_row_stride_bytes, &p))) return rc;
     if (launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
     return EU_OK;
@@ -496,8 +601,13 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   const size_t rows = (size_t)(trg->row_end - trg->row_begin);
   if (!rows) return EU_OK;
   if ((rc = grow(&g.stage, &g.stage_cap, rows * trg->width * och))) return rc;
-  if ((rc = build_params(trg, srcs, nsrc, g.stage, min_stride, &p))) return rc;
-  if (launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+  if (multi) {
+    if ((rc = build_multi(trg, srcs, nsrc, g.stage, min_stride, &mp, &mdeg))) return rc;
+    if (eu_launch_render_multi(&mp, mdeg, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+  } else {
+    if ((rc = build_params(trg, srcs, nsrc, g.stage, min_stride, &p))) return rc;
+    if (launch_render(&p, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+  }
   HIPCHK(hipMemcpy2DAsync(out, out_row_stride_bytes, g.stage, min_stride, min_stride, rows,
                           hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

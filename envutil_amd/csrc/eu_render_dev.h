@@ -420,21 +420,21 @@ __device__ __forceinline__ float eu_norm3(float x, float y, float z)
 }
 
 // full stepper: tables -> ray, with the normalisation flavour of the stepper
-__device__ __forceinline__ void eu_stepper(const eu_render_params &p, const float *colA,
+__device__ __forceinline__ void eu_stepper(int form, int norm_mode, const float *colA,
                                            const float *colB, const float *rowt, int x,
                                            float &rx, float &ry, float &rz)
 {
-  eu_ray(p.form, rowt, colA[x], colB[x], rx, ry, rz);
-  if (p.norm_mode == EU_NORM_DIV) {
+  eu_ray(form, rowt, colA[x], colB[x], rx, ry, rz);
+  if (norm_mode == EU_NORM_DIV) {
     float n = eu_norm3(rx, ry, rz);
     rx = rx / n; ry = ry / n; rz = rz / n;
-  } else if (p.norm_mode == EU_NORM_CYL) {
+  } else if (norm_mode == EU_NORM_CYL) {
     // cylindrical_stepper keeps the reciprocal length of the lane's FIRST
     // pixel in the 512-pixel segment (stepper.h:771-775, :786)
     int seg = (x / EU_SEGMENT) * EU_SEGMENT;
     int x0 = seg + ((x - seg) % EU_LANES);
     float fx, fy, fz;
-    eu_ray(p.form, rowt, colA[x0], colB[x0], fx, fy, fz);
+    eu_ray(form, rowt, colA[x0], colB[x0], fx, fy, fz);
     float rcp = 1.0f / eu_norm3(fx, fy, fz);
     rx = rx * rcp; ry = ry * rcp; rz = rz * rcp;
   }
@@ -465,5 +465,12 @@ static inline int eu_xcd_grid(int tiles_x, int tiles_y, int unit_rows)
 }
 
 #define EU_UNIT_ROWS 8
+
+__device__ __forceinline__ void eu_stepper(const eu_render_params &p, const float *colA,
+                                           const float *colB, const float *rowt, int x,
+                                           float &rx, float &ry, float &rz)
+{
+  eu_stepper(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz);
+}
 
 #endif

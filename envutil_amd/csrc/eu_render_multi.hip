@@ -1,0 +1,250 @@
+// Multi-facet rendering: N steppers (one per source facet, each with that
+// facet's composed rotation) feed a synopsis that picks / composites the facets
+// per pixel.
+//   fusion_t                zimt/get.h:1181-1242
+//   synopsis_t (twining)    envutil_payload.cc:587-691
+//   _voronoi_syn            envutil_payload.cc:762-957   (1 or 3 channels)
+//   _voronoi_syn_plus       envutil_payload.cc:964-1233  (alpha: 2 or 4 channels)
+//
+// One thread per output pixel, 64x4 tiles like eu_render_kernel. The reference
+// takes three decisions per 16-lane VECTOR (which facets enter the layer list,
+// "one facet on top everywhere", "fully opaque"); a wavefront holds four such
+// vectors (its 64 pixels start at a multiple of 64 inside a 512-pixel segment),
+// so those decisions are wavefront ballots masked to 16-lane groups - the
+// reference's any_of/all_of, bit for bit.
+//
+// Facets whose evaluation differs between lanes are handled by a waterfall loop:
+// the facet index is made wave-uniform (readfirstlane) so that its parameters
+// come through the scalar cache, and the lanes that want it evaluate together.
+#include "eu_render_dev.h"
+
+#define EU_MULTI_MAXF 16
+
+struct eu_multi_params {
+  int width, height, row_begin, row_end;
+  int form, norm_mode, twine, ntaps, nch, nfct, plus;
+  const float *col;          // [4][width], shared by all facets
+  const float *row;          // [nfct][height][EU_ROW_FLOATS]
+  const float *taps;         // [ntaps][3], x/y scaled by 4
+  const eu_src_dev *srcs;    // [nfct]
+  float *out;
+  long long out_stride;
+  int tiles_x, tiles_y;
+};
+
+struct eu_pix { int x, y; };
+
+// ray of facet f for this pixel; variant 0: r00, 1: x-biased, 2: y-biased
+__device__ __forceinline__ void eu_multi_ray(const eu_multi_params &p, int f, int variant,
+                                             const eu_pix &px, float &rx, float &ry, float &rz)
+{
+  const float *rowt = p.row + ((long long)f * p.height + px.y) * EU_ROW_FLOATS
+                      + (variant == 2 ? EU_ROW_VARIANT : 0);
+  const float *ca = variant == 1 ? p.col + 2 * p.width : p.col;
+  eu_stepper(p.form, p.norm_mode, ca, ca + p.width, rowt, px.x, rx, ry, rz);
+}
+
+// the ray the synopsis sees for facet f: the stepper's, or the twining tap's
+// p0 + cx * du + cy * dv (payload.cc:669-675)
+__device__ __forceinline__ void eu_syn_ray(const eu_multi_params &p, int f, const eu_pix &px,
+                                           bool tap, float cx, float cy, float &rx, float &ry,
+                                           float &rz)
+{
+  eu_multi_ray(p, f, 0, px, rx, ry, rz);
+  if (tap) {
+    float ax, ay, az, bx, by, bz;
+    eu_multi_ray(p, f, 1, px, ax, ay, az);
+    eu_multi_ray(p, f, 2, px, bx, by, bz);
+    float dux = ax - rx, duy = ay - ry, duz = az - rz;
+    float dvx = bx - rx, dvy = by - ry, dvz = bz - rz;
+    rx = rx + cx * dux + cy * dvx;
+    ry = ry + cx * duy + cy * dvy;
+    rz = rz + cx * duz + cy * dvz;
+  }
+}
+
+// evaluate facet `want` (wave-divergent, -1: none) for this lane
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want, const eu_pix &px,
+                                              bool tap, float cx, float cy, float *out)
+{
+#pragma unroll
+  for (int c = 0; c < NCH; c++) out[c] = 0.0f;
+  int pending = want;
+  while (true) {
+    unsigned long long m = __ballot(pending >= 0);
+    if (!m) break;
+    int first = __ffsll((long long)m) - 1;
+    int f = __builtin_amdgcn_readlane(pending, first);
+    if (pending == f) {
+      float rx, ry, rz;
+      eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+      eu_environment<NCH, DEG>(p.srcs[f], rx, ry, rz, out);
+      pending = -1;
+    }
+  }
+}
+
+// one synopsis evaluation for this lane
+template <int NCH, int DEG, bool PLUS>
+__device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_pix &px,
+                                            bool live, bool tap, float cx, float cy, float *out)
+{
+  const int nf = p.nfct;
+  float zs[EU_MULTI_MAXF];
+  unsigned valid = 0;
+  // get_mask + z score of every facet
+#pragma unroll
+  for (int f = 0; f < EU_MULTI_MAXF; f++) {
+    zs[f] = 0.0f;
+    if (f < nf) {
+      float rx, ry, rz, sx, sy;
+      int face;
+      eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+      const eu_src_dev &s = p.srcs[f];
+      bool hit = s.mask_all ? true : eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+      if (hit && live) valid |= 1u << f;
+      zs[f] = rz * s.recip_step;
+    }
+  }
+  if constexpr (!PLUS) {
+    // _voronoi_syn: largest z wins, strict '>' keeps the earlier facet
+    int champ = -1;
+    float max_z = -3.402823466e+38f;          // numeric_limits<float>::lowest()
+    if (valid & 1u) { champ = 0; max_z = zs[0]; }
+#pragma unroll
+    for (int f = 1; f < EU_MULTI_MAXF; f++)
+      if (f < nf && ((valid >> f) & 1u) && zs[f] > max_z) { champ = f; max_z = zs[f]; }
+    eu_eval_facet<NCH, DEG>(p, champ, px, tap, cx, cy, out);
+    return;
+  } else {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 4;
+    const unsigned long long live_m = __ballot(live);
+    const unsigned live_g = (unsigned)(live_m >> (16 * grp)) & 0xffffu;
+    // next_best of this lane's vector: the last facet valid for any of its lanes
+    int next_best = -1;
+#pragma unroll
+    for (int f = 0; f < EU_MULTI_MAXF; f++)
+      if (f < nf) {
+        unsigned long long b = __ballot((valid >> f) & 1u);
+        if ((unsigned)(b >> (16 * grp)) & 0xffffu) next_best = f;
+      }
+    // layer 0 of this lane
+    auto pick = [&](unsigned used) {
+      int best = -1;
+      float bz = 0.0f;
+#pragma unroll
+      for (int f = 0; f < EU_MULTI_MAXF; f++)
+        if (f < nf && ((valid >> f) & 1u) && !((used >> f) & 1u)) {
+          if (best < 0 || zs[f] > bz) { best = f; bz = zs[f]; }
+        }
+      return best;
+    };
+    const int top = pick(0u);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) out[c] = 0.0f;
+    bool done = !live;
+    if (next_best < 0) done = true;           // layers == 0 for this vector
+    // "one facet on top of the whole vector" + "opaque everywhere": take it as is
+    {
+      unsigned long long tm = __ballot(live && top == next_best);
+      bool all_top = !done && ((unsigned)(tm >> (16 * grp)) & 0xffffu) == live_g;
+      float help[NCH];
+      eu_eval_facet<NCH, DEG>(p, all_top ? next_best : -1, px, tap, cx, cy, help);
+      unsigned long long om = __ballot(all_top && help[NCH - 1] >= 1.0f);
+      bool opaque = all_top && ((unsigned)(om >> (16 * grp)) & 0xffffu) == live_g;
+      if (opaque) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) out[c] = help[c];
+        done = true;
+      }
+    }
+    // general path: composite the lane's valid facets, nearest first
+    unsigned used = 0;
+    int layer = 0;
+    while (true) {
+      int f = done ? -1 : pick(used);
+      if (!__ballot(f >= 0)) break;
+      float help[NCH];
+      eu_eval_facet<NCH, DEG>(p, f, px, tap, cx, cy, help);
+      if (f >= 0) {
+        used |= 1u << f;
+        if (layer == 0) {
+#pragma unroll
+          for (int c = 0; c < NCH; c++) out[c] = help[c];
+        } else {
+          const float a = out[NCH - 1];
+#pragma unroll
+          for (int c = 0; c < NCH; c++) out[c] = out[c] + (1.0f - a) * help[c];
+        }
+        layer++;
+      }
+    }
+  }
+}
+
+template <int NCH, int DEG, bool PLUS>
+__global__ __launch_bounds__(256) void eu_render_multi_kernel(const eu_multi_params p)
+{
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
+  if (b < 0) return;
+  const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
+  const int lane = threadIdx.x & 63;
+  const int wrow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  eu_pix px;
+  px.x = tile_x * EU_TILE_W + lane;
+  px.y = p.row_begin + tile_y * EU_TILE_H + wrow;
+  if (px.y >= p.row_end) return;              // wave-uniform
+  const bool live = px.x < p.width;
+  if (!live) px.x = p.width - 1;              // keeps table reads in range; no store
+  float out[NCH];
+  if (!p.twine) {
+    eu_synopsis<NCH, DEG, PLUS>(p, px, live, false, 0.0f, 0.0f, out);
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) out[c] = 0.0f;
+    for (int k = 0; k < p.ntaps; k++) {
+      const float cx = p.taps[3 * k], cy = p.taps[3 * k + 1], cw = p.taps[3 * k + 2];
+      float help[NCH];
+      eu_synopsis<NCH, DEG, PLUS>(p, px, live, true, cx, cy, help);
+#pragma unroll
+      for (int c = 0; c < NCH; c++) out[c] = out[c] + cw * help[c];
+    }
+  }
+  if (!live) return;
+  float *o = p.out + (long long)(px.y - p.row_begin) * p.out_stride + (long long)px.x * NCH;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) o[c] = out[c];
+}
+
+template <int NCH, bool PLUS>
+static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
+{
+  dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), block(256);
+  switch (degree) {
+    case 0: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 0, PLUS>), grid, block, 0, st, p); break;
+    case 1: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 1, PLUS>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 2, PLUS>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 3, PLUS>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, PLUS>), grid, block, 0, st, p); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int eu_launch_render_multi(const void *pp, int degree, void *stream)
+{
+  eu_multi_params p = *(const eu_multi_params *)pp;
+  if (p.nfct > EU_MULTI_MAXF) return -3;
+  p.tiles_x = (p.width + EU_TILE_W - 1) / EU_TILE_W;
+  p.tiles_y = (p.row_end - p.row_begin + EU_TILE_H - 1) / EU_TILE_H;
+  if (p.tiles_x <= 0 || p.tiles_y <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (p.nch) {
+    case 1: return launch_multi_n<1, false>(p, degree, st);
+    case 3: return launch_multi_n<3, false>(p, degree, st);
+    case 2: return launch_multi_n<2, true>(p, degree, st);
+    case 4: return launch_multi_n<4, true>(p, degree, st);
+  }
+  return -2;
+}

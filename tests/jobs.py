@@ -98,7 +98,11 @@ class OracleSource:
 
 
 def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8):
-    """args: envutil_amd.arguments (only its plain fields are read)"""
+    """args: envutil_amd.arguments (only its plain fields are read); osrc: one
+    OracleSource or a list of them (multi-facet job)"""
+    srcs = osrc if isinstance(osrc, (list, tuple)) else [osrc]
+    osrc = srcs[0]
+    arr = (euo.Source * len(srcs))(*[o.s for o in srcs])
     j = euo.Job()
     j.projection = args.projection
     j.width, j.height = args.width, args.height
@@ -116,7 +120,7 @@ def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8):
     j.nthreads = nthreads
     och = 3 if stage else osrc.nch
     out = np.zeros((j.row_end - j.row_begin, args.width, och), np.float32)
-    rc = euo.lib().euo_render(C.byref(j), C.byref(osrc.s), 1, euo.ptr(out), args.width * och)
+    rc = euo.lib().euo_render(C.byref(j), arr, len(srcs), euo.ptr(out), args.width * och)
     assert rc == 0, rc
     return out
 

@@ -188,3 +188,69 @@ def test_identity_reprojection_property(latlon):
     g = ea.Source.load(fct, latlon[3], 3)
     a = ea.arguments(ea.SPHERICAL, SRC_W, SRC_H, 360.0, spline_degree=3)
     assert np.abs(ea.render(a, g) - latlon[3]).max() < 2e-4
+
+
+# ---- multi-facet jobs: fusion_t + voronoi synopsis --------------------------
+
+def facet_set(prj, w, h, hfov, nch, degree, lens=None, seed=0):
+    """six facets looking front/right/back/left/up/down (BASELINE config 5 shape)"""
+    views = [(0, 0, 0), (90, 0, 3), (180, 0, -2), (270, 0, 1), (0, 90, 0), (0, -90, 5)]
+    os_, gs = [], []
+    for i, (yaw, pitch, roll) in enumerate(views):
+        img = jobs.synth_image(w, h, nch, seed=seed + 17 * i)
+        if nch in (2, 4):
+            # feathered alpha so that compositing below the top layer matters
+            yy, xx = np.mgrid[0:h, 0:w]
+            r = np.hypot((xx - w / 2) / (w / 2), (yy - h / 2) / (h / 2))
+            img[:, :, nch - 1] = np.clip(1.6 - 1.4 * r, 0.0, 1.0)
+            img[:, :, :nch - 1] *= img[:, :, nch - 1:]
+        o = jobs.OracleSource(prj, w, h, hfov, img, degree, yaw=yaw, pitch=pitch, roll=roll,
+                              brighten=1.0 + 0.05 * i, lens=lens)
+        g = ea.Source.adopt(ea.facet_spec(prj, w, h, hfov, nchannels=nch, yaw=yaw, pitch=pitch,
+                                          roll=roll, brighten=1.0 + 0.05 * i, lens=lens),
+                            o.container, degree, o.bc[0], o.bc[1])
+        os_.append(o)
+        gs.append(g)
+    return os_, gs
+
+
+@pytest.mark.parametrize("nch", [3, 4])
+@pytest.mark.parametrize("degree", [1, 3])
+def test_multi_facet_fisheye_stitch_bit_exact(nch, degree):
+    """config 5 at test size: six circular-fisheye facets with the PTO lens
+    polynomial -> spherical; voronoi_syn (RGB) / voronoi_syn_plus (RGBA)"""
+    lens = dict(a=0.01, b=-0.03, c=0.02)
+    os_, gs = facet_set(euo.FISHEYE, 96, 96, 130.0, nch, degree, lens)
+    a = ea.arguments(ea.SPHERICAL, 300, 150, 360.0, yaw=10, pitch=4, roll=-2, spline_degree=degree)
+    got, ref = ea.render(a, gs, nch), jobs.oracle_render(a, os_)
+    assert_bits(got, ref, f"multi-facet nch {nch} degree {degree}")
+    assert (ref[:, :, 0] != 0).mean() > 0.9
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3, 4])
+def test_multi_facet_rectilinear_and_holes(nch):
+    """rectilinear facets with 100 degree fov leave no hole; with 70 degrees
+    they do (champion -1 -> 0); targets other than spherical"""
+    for hfov in (100.0, 70.0):
+        os_, gs = facet_set(euo.RECTILINEAR, 80, 80, hfov, nch, 1, seed=5)
+        for tprj, tw, th, thfov in [(ea.CUBEMAP, 40, 240, 90.0), (ea.RECTILINEAR, 111, 77, 120.0)]:
+            a = ea.arguments(tprj, tw, th, thfov, yaw=33, pitch=12, roll=5, spline_degree=1)
+            assert_bits(ea.render(a, gs, nch), jobs.oracle_render(a, os_), f"rect facets {hfov} {tprj}")
+
+
+@pytest.mark.parametrize("nch", [3, 4])
+def test_multi_facet_twining_bit_exact(nch):
+    os_, gs = facet_set(euo.FISHEYE, 64, 64, 140.0, nch, 1)
+    a = ea.arguments(ea.SPHERICAL, 130, 65, 360.0, yaw=5, spline_degree=1, twine=2)
+    assert_bits(ea.render(a, gs[:4], nch), jobs.oracle_render(a, os_[:4]), "multi-facet twining")
+
+
+def test_multi_facet_mixed_projections():
+    """facets of different projections in one job (a lat/lon backdrop under
+    rectilinear insets)"""
+    back = jobs.synth_image(256, 128, 3, seed=1)
+    o0 = jobs.OracleSource(euo.SPHERICAL, 256, 128, 360.0, back, 3)
+    g0 = ea.Source.adopt(ea.facet_spec(ea.SPHERICAL, 256, 128, 360.0), o0.container, 3, o0.bc[0], o0.bc[1])
+    os_, gs = facet_set(euo.RECTILINEAR, 64, 48, 50.0, 3, 3, seed=9)
+    a = ea.arguments(ea.SPHERICAL, 256, 128, 360.0, spline_degree=3)
+    assert_bits(ea.render(a, [g0] + gs[:3], 3), jobs.oracle_render(a, [o0] + os_[:3]), "mixed facets")
