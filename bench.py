@@ -37,6 +37,9 @@ WORKLOADS = {
     "config3": (("cubemap", 2048, 12288, 90.0), ("spherical", 16384, 8192, 360.0), 3, 3, 0, (0, 0, 0)),
     "config4": (("spherical", 32768, 16384, 360.0), ("spherical", 32768, 16384, 360.0), 3, 1, 3, (30, 15, 7.5)),
     "small": (("spherical", 2048, 1024, 360.0), ("cubemap", 512, 3072, 90.0), 3, 3, 0, (0, 0, 0)),
+    # BASELINE config 5: six 8192^2 RGBA circular-fisheye facets (hfov 130, yaw 0/90/180/270 +
+    # pitch +-90, PTO lens a=.01 b=-.03 c=.02) -> 16384x8192 spherical, voronoi_syn_plus
+    "config5": (("fisheye", 8192, 8192, 130.0), ("spherical", 16384, 8192, 360.0), 4, 1, 0, (0, 0, 0)),
     # diagnostic shapes (not bench lines): headline-sized target, cache-resident source
     "probe_smallsrc": (("spherical", 2048, 1024, 360.0), ("cubemap", 4096, 24576, 90.0), 3, 3, 0, (0, 0, 0)),
     "probe_bilinear": (("spherical", 16384, 8192, 360.0), ("cubemap", 4096, 24576, 90.0), 3, 1, 0, (0, 0, 0)),
@@ -47,6 +50,7 @@ WORKLOAD_TEXT = {
     "config3": "6x2048 cubemap -> 16384x8192 spherical, b-spline degree 3 + prefilter, RGB f32",
     "config4": "32768x16384 lat/lon -> 32768x16384 spherical, ypr 30/15/7.5, 3x3 twining, bilinear, RGB f32",
     "small": "2048x1024 lat/lon -> 6x512 cubemap, b-spline degree 3 (smoke size)",
+    "config5": "6 x 8192^2 RGBA fisheye facets (hfov 130, lens a/b/c) -> 16384x8192 spherical, bilinear, voronoi_syn_plus",
     "probe_smallsrc": "DIAGNOSTIC 2048x1024 lat/lon -> 6x4096 cubemap, degree 3",
     "probe_bilinear": "DIAGNOSTIC 16384x8192 lat/lon -> 6x4096 cubemap, bilinear",
 }
@@ -113,35 +117,47 @@ def main():
     sprj, tprj = PROJECTION_NAMES.index(sname), PROJECTION_NAMES.index(tname)
 
     # ---- set-up (untimed): source coefficients into HBM on every rank ------
-    fct = ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch)
-    t_setup = time.time()
-    if rank == 0:
-        img = synth_on_device(torch, dev, sw, sh, nch)
-        host = img.cpu().numpy()
-        del img
-        torch.cuda.empty_cache()
-        src = ea.Source.load(fct, host, degree)          # H2D + device prefilter/brace
-        del host
+    if a.workload == "config5":
+        views = [(0, 0, 0), (90, 0, 0), (180, 0, 0), (270, 0, 0), (0, 90, 0), (0, -90, 0)]
+        fcts = [ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch, yaw=v[0], pitch=v[1], roll=v[2],
+                              lens=dict(a=0.01, b=-0.03, c=0.02)) for v in views]
     else:
-        src = ea.Source.alloc(fct, degree)
-    if world > 1:
-        ptr, n = src.device_ptr()
-        buf = torch.as_tensor(_DevBuf(ptr, n), device=dev)
-        dist.broadcast(buf, 0)                           # RCCL over xGMI, once per source
-        torch.cuda.synchronize()
+        fcts = [ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch)]
+    t_setup = time.time()
+    sources = []
+    for fct in fcts:
+        if rank == 0:
+            img = synth_on_device(torch, dev, sw, sh, nch)
+            if nch in (2, 4):
+                img[:, :, nch - 1] = 1.0
+            host = img.cpu().numpy()
+            del img
+            torch.cuda.empty_cache()
+            s1 = ea.Source.load(fct, host, degree)       # H2D + device prefilter/brace
+            del host
+        else:
+            s1 = ea.Source.alloc(fct, degree)
+        if world > 1:
+            ptr, n = s1.device_ptr()
+            buf = torch.as_tensor(_DevBuf(ptr, n), device=dev)
+            dist.broadcast(buf, 0)                       # RCCL over xGMI, once per source
+            torch.cuda.synchronize()
+        sources.append(s1)
+    src = sources[0]
     t_setup = time.time() - t_setup
 
     args = ea.arguments(tprj, tw, th, thfov, yaw=ypr[0], pitch=ypr[1], roll=ypr[2],
                         spline_degree=degree, twine=twine)
-    # row tile of this rank
-    r0 = (th * rank) // world
-    r1 = (th * (rank + 1)) // world
+    # row strip of this rank (multiples of the 4-row tile height)
+    from envutil_amd.distributed import row_partition, gather_strips
+    r0, r1 = row_partition(th, world, rank, align=4)
     out = torch.empty(((r1 - r0), tw, nch), device=dev, dtype=torch.float32)
-    srcs = (C.c_void_p * 1)(src.handle)
+    srcs = (C.c_void_p * len(sources))(*[x.handle for x in sources])
+    nsrcs = len(sources)
     tgt = args.target(nch, r0, r1, 0)
 
     def step():
-        rc = ea.lib().eu_hip_render(C.byref(tgt), srcs, 1, C.c_void_p(out.data_ptr()),
+        rc = ea.lib().eu_hip_render(C.byref(tgt), srcs, nsrcs, C.c_void_p(out.data_ptr()),
                                     tw * nch * 4, 1, None)
         if rc:
             raise SystemExit("render failed: " + ea.lib().eu_hip_last_error().decode())
@@ -168,8 +184,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- final gather of the strips on rank 0 (outside the timed steps) -------
+    gather_ms = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        frame = gather_strips(dist, out, th, tw, nch, rank, world, dst=0, align=4)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = 1e3 * (time.perf_counter() - tg)
+        del frame
+
     # ---- kernel-only time with HIP events on the kernel's stream ------------
-    kernel_ms = ea.render_timed(args, src, out.data_ptr(), max(a.steps, 5), nch, r0, r1)
+    if nsrcs == 1:
+        kernel_ms = ea.render_timed(args, src, out.data_ptr(), max(a.steps, 5), nch, r0, r1)
+    else:
+        kernel_ms = 1e3 * elapsed / a.steps     # multi-facet: no separate event path yet; step time
 
     probe = None
     if a.probe_stages:
@@ -194,6 +225,7 @@ def main():
         n_src = sec * 6 * sec
     else:
         n_src = sw * sh
+    n_src *= nsrcs
     src_share = n_src if world == 1 else n_src / world
     alg_bytes = 4.0 * nch * (src_share + npix_rank)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -224,16 +256,17 @@ def main():
         "config": {"workload": WORKLOAD_TEXT[a.workload], "name": a.workload,
                    "channels": nch, "spline_degree": degree, "twine": twine,
                    "rows_per_gpu": r1 - r0, "tiling": f"rows/{world}",
+                   "gather_ms_untimed": None if gather_ms is None else round(gather_ms, 3),
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic,
-                     "kernel": "eu_render2_kernel (packed two-pixel)" if (twine == 0 and sprj == 0 and degree in (1, 2, 3)) else "eu_render_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "kernel": "eu_render_multi_kernel" if nsrcs > 1 else ("eu_render2_kernel (packed two-pixel)" if (sprj in (0, 5, 6) and degree in (1, 2, 3)) else "eu_render_kernel"), "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": alg_bytes},
     }
 
     # ---- CPU baseline: the oracle (a port) on a band of rows, rank 0, N=1 ----
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and nsrcs == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import euo
         import jobs

@@ -227,8 +227,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     return fail(EU_ERR_UNSUPPORTED, "multi-facet synopsis (voronoi_syn) not built yet: nsrc must be 1");
   const eu_source *s = srcs[0];
   if (!s) return fail(EU_ERR_HANDLE, "null source");
-  if (t->nchannels != s->nch)
-    return fail(EU_ERR_UNSUPPORTED, "channel adaption (repix_t) not built yet: target and source channel counts differ");
+  if (t->nchannels < 1 || t->nchannels > 4) return fail(EU_ERR_ARGUMENT, "target channels must be 1..4");
   if (t->width <= 0 || t->height <= 0) return fail(EU_ERR_ARGUMENT, "empty target");
   if (t->row_begin < 0 || t->row_end > t->height || t->row_begin > t->row_end)
     return fail(EU_ERR_ARGUMENT, "row range outside the target");
@@ -283,6 +282,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   p->row_begin = t->row_begin; p->row_end = t->row_end;
   p->form = form; p->norm_mode = norm_mode;
   p->twine = twine; p->ntaps = t->ntaps; p->stage = t->stage; p->nch = s->nch;
+  p->nch_out = t->nchannels;
   p->col = g.col; p->row = g.row; p->taps = g.taps;
   p->out = out_dev;
   p->out_stride = (long long)(row_stride_bytes / sizeof(float));

@@ -52,7 +52,8 @@ struct eu_src_dev {
 
 struct eu_render_params {
   int width, height, row_begin, row_end;
-  int form, norm_mode, twine, ntaps, stage, nch;
+  int form, norm_mode, twine, ntaps, stage, nch;   // nch: channels of the source
+  int nch_out;               // channels of the target (repix_t when they differ)
   const float *col;          // [4][width]: c0, c1, c0 (x-biased), c1 (x-biased)
   const float *row;          // [height][EU_ROW_FLOATS]
   const float *taps;         // [ntaps][3], x and y already scaled by 4

@@ -66,6 +66,30 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
     return;
   }
 
+  if (p.nch_out != NCH) {
+    // channel adaption (repix_t): the source has NCH channels, the target nch_out
+    const int on = p.nch_out;
+    float q4[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if constexpr (!TWINE) {
+      eu_environment_repix<NCH, DEG>(p.src, on, rx, ry, rz, acc);
+    } else {
+      const float *col2 = p.col + 2 * p.width, *col3 = p.col + 3 * p.width;
+      float ax, ay, az, bx, by, bz;
+      eu_stepper(p, col2, col3, rowt, x, ax, ay, az);
+      eu_stepper(p, col0, col1, rowt + EU_ROW_VARIANT, x, bx, by, bz);
+      float dxx = ax - rx, dxy = ay - ry, dxz = az - rz;
+      float dyx = bx - rx, dyy = by - ry, dyz = bz - rz;
+      for (int k = 0; k < p.ntaps; k++) {
+        float cx = p.taps[3 * k], cy = p.taps[3 * k + 1], cw = p.taps[3 * k + 2];
+        eu_environment_repix<NCH, DEG>(p.src, on, rx + cx * dxx + cy * dyx, ry + cx * dxy + cy * dyy,
+                                       rz + cx * dxz + cy * dyz, q4);
+        for (int c = 0; c < on; c++) acc[c] = acc[c] + cw * q4[c];
+      }
+    }
+    float *o4 = dst + (long long)x * on;
+    for (int c = 0; c < on; c++) o4[c] = acc[c];
+    return;
+  }
   float px[NCH];
   if constexpr (!TWINE) {
     eu_environment<NCH, DEG>(p.src, rx, ry, rz, px);
@@ -223,7 +247,7 @@ static hipError_t launch_nd(const eu_render_params &p, hipStream_t st)
 {
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), block(256);
   if (p.twine) hipLaunchKernelGGL((eu_render_kernel<NCH, DEG, true>), grid, block, 0, st, p);
-  else if (DEG >= 1 && p.stage == 0 && !p.direct) {
+  else if (DEG >= 1 && p.stage == 0 && !p.direct && p.nch_out == p.nch) {
     if constexpr (DEG >= 1) hipLaunchKernelGGL((eu_render_lds_kernel<NCH, DEG>), grid, block, 0, st, p);
   }
   else hipLaunchKernelGGL((eu_render_kernel<NCH, DEG, false>), grid, block, 0, st, p);

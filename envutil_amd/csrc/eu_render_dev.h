@@ -355,6 +355,71 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
   return mask;
 }
 
+// repix_t, environment.h:1205-1309: channel-count adaption IN -> out_n
+template <int IN>
+__device__ __forceinline__ void eu_repix(int out_n, const float *in, float *out)
+{
+  if constexpr (IN == 1) {
+    out[0] = in[0]; out[1] = in[0]; out[2] = in[0];
+    if (out_n == 2) out[1] = 1.0f;
+    if (out_n == 4) out[3] = 1.0f;
+  } else if constexpr (IN == 2) {
+    if (out_n == 4) { out[0] = in[0]; out[1] = in[0]; out[2] = in[0]; out[3] = in[1]; }
+    else {
+      float v = in[0] / in[1];
+      if (in[1] == 0.0f) v = 0.0f;
+      out[0] = v; out[1] = v; out[2] = v;
+    }
+  } else if constexpr (IN == 3) {
+    if (out_n == 4) { out[0] = in[0]; out[1] = in[1]; out[2] = in[2]; out[3] = 1.0f; }
+    else {
+      float sum = in[0]; sum = sum + in[1]; sum = sum + in[2];
+      out[0] = sum / 3.0f; out[1] = 1.0f;
+    }
+  } else {
+    if (out_n == 1) {
+      float v = (in[0] + in[1] + in[2]) / 3.0f;
+      v = v / in[3];
+      if (in[3] == 0.0f) v = 0.0f;
+      out[0] = v;
+    } else if (out_n == 2) {
+      out[0] = (in[0] + in[1] + in[2]) / 3.0f; out[1] = in[3];
+    } else {
+      out[0] = in[0] / in[3]; out[1] = in[1] / in[3]; out[2] = in[2] / in[3];
+      if (in[3] == 0.0f) { out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; }
+    }
+  }
+}
+
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
+                                               float rz, float *px);
+
+// environment::eval for a target with out_n != NCH channels: inner evaluation,
+// repix, brighten on the OUTPUT layout (environment.h:1821-1842, :1859-1900).
+// px has room for 4 floats.
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_environment_repix(const eu_src_dev &s, int out_n, float rx,
+                                                     float ry, float rz, float *px)
+{
+  float sx, sy;
+  int face;
+  float raw[NCH];
+  bool hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+  if (hit) {
+    if constexpr (DEG >= 0) eu_bspline<NCH, DEG>(s, sx, sy, raw);
+    else eu_bspline_generic<NCH>(s, sx, sy, raw);
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) raw[c] = 0.0f;
+  }
+  eu_repix<NCH>(out_n, raw, px);
+  if (s.brighten != 1.0f) {
+    const int ncol = (out_n == 2 || out_n == 4) ? out_n - 1 : out_n;
+    for (int c = 0; c < ncol; c++) px[c] = px[c] * s.brighten;
+  }
+}
+
 template <int NCH, int DEG>
 __device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
                                                float rz, float *px)

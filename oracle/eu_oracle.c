@@ -1317,6 +1317,53 @@ static void brighten_px(const mount_t *m, float *px)
   }
 }
 
+/* repix_t, environment.h:1205-1309: channel-count adaption */
+static void repix(int in_n, int out_n, const float *in, float *out)
+{
+  if (in_n == out_n) { for (int c = 0; c < in_n; c++) out[c] = in[c]; return; }
+  if (in_n == 1) {
+    if (out_n == 3) { out[0] = out[1] = out[2] = in[0]; }
+    else if (out_n == 2) { out[0] = in[0]; out[1] = 1.0f; }
+    else { out[0] = out[1] = out[2] = in[0]; out[3] = 1.0f; }
+  } else if (in_n == 2) {
+    if (out_n == 1 || out_n == 3) {
+      float v = in[0] / in[1];
+      if (in[1] == 0.0f) v = 0.0f;
+      for (int c = 0; c < out_n; c++) out[c] = v;
+    } else { out[0] = out[1] = out[2] = in[0]; out[3] = in[1]; }
+  } else if (in_n == 3) {
+    float sum = in[0]; sum += in[1]; sum += in[2];
+    if (out_n == 1) out[0] = sum / 3.0f;
+    else if (out_n == 2) { out[0] = sum / 3.0f; out[1] = 1.0f; }
+    else { out[0] = in[0]; out[1] = in[1]; out[2] = in[2]; out[3] = 1.0f; }
+  } else {
+    if (out_n == 1) {
+      float v = (in[0] + in[1] + in[2]) / 3.0f;
+      v /= in[3];
+      if (in[3] == 0.0f) v = 0.0f;
+      out[0] = v;
+    } else if (out_n == 2) { out[0] = (in[0] + in[1] + in[2]) / 3.0f; out[1] = in[3]; }
+    else {
+      for (int c = 0; c < 3; c++) out[c] = in[c] / in[3];
+      if (in[3] == 0.0f) out[0] = out[1] = out[2] = 0.0f;
+    }
+  }
+}
+
+/* environment::eval (environment.h:1821-1842) for a target with out_n channels:
+ * inner evaluation, channel adaption, then brighten on the OUTPUT layout */
+static void env_eval(const mount_t *m, const float *ray, int out_n, float *px, float *dbg)
+{
+  float raw[4];
+  int in_n = m->src->spl.nch;
+  mount_eval(m, ray, raw, dbg);
+  repix(in_n, out_n, raw, px);
+  if (m->brighten != 1.0f) {
+    int ncol = (out_n == 2 || out_n == 4) ? out_n - 1 : out_n;
+    for (int c = 0; c < ncol; c++) px[c] *= m->brighten;
+  }
+}
+
 /* lens polynomial + shift + shear, PTO forward direction
  * (environment.h:254-284; lens_correction.h:93-105, :224-235). The flags and
  * the scale s come from process_geometry (envutil_basic.h:499-521). */
@@ -1572,7 +1619,6 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
   if (nsrc != 1) return -2;
   const euo_source *src = &srcs[0];
   int nch = job->nch;
-  if (src->spl.nch != nch) return -3;
   double r_cam[9], r_fct[9], basis[9];
   euo_make_r3(job->roll, job->pitch, job->yaw, 0, r_cam);
   euo_make_r3(src->roll, src->pitch, src->yaw, 1, r_fct);
@@ -1612,12 +1658,11 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
         continue;
       }
       if (!twining) {
-        mount_eval(&mnt, ray, px, dbg);
+        env_eval(&mnt, ray, nch, px, dbg);
         if (job->stage == 2) {
           row[3 * x] = dbg[0]; row[3 * x + 1] = dbg[1]; row[3 * x + 2] = dbg[2];
           continue;
         }
-        brighten_px(&mnt, px);
         for (int c = 0; c < nch; c++) row[(long)x * nch + c] = px[c];
       } else {
         float r10[3], r01[3], dx[3], dy[3], acc[4] = { 0, 0, 0, 0 };
@@ -1628,8 +1673,7 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
           float in_k[3];
           for (int i = 0; i < 3; i++)
             in_k[i] = ray[i] + taps[3 * k] * dx[i] + taps[3 * k + 1] * dy[i];
-          mount_eval(&mnt, in_k, px, NULL);
-          brighten_px(&mnt, px);
+          env_eval(&mnt, in_k, nch, px, NULL);
           for (int c = 0; c < nch; c++) acc[c] += taps[3 * k + 2] * px[c];
         }
         for (int c = 0; c < nch; c++) row[(long)x * nch + c] = acc[c];

@@ -97,7 +97,7 @@ class OracleSource:
         self.degree = spline_degree
 
 
-def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8):
+def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8, nch=None):
     """args: envutil_amd.arguments (only its plain fields are read); osrc: one
     OracleSource or a list of them (multi-facet job)"""
     srcs = osrc if isinstance(osrc, (list, tuple)) else [osrc]
@@ -108,7 +108,7 @@ def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8):
     j.width, j.height = args.width, args.height
     j.x0, j.x1, j.y0, j.y1 = (float(v) for v in args.extent)
     j.yaw, j.pitch, j.roll = (math.radians(v) for v in (args.yaw, args.pitch, args.roll))
-    j.nch = osrc.nch
+    j.nch = nch or osrc.nch
     taps = None
     if args.twine_spread is not None:
         taps = np.ascontiguousarray(args.twine_spread, np.float32)
@@ -118,7 +118,7 @@ def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8):
     j.row_end = args.height if row_end is None else row_end
     j.stage = stage
     j.nthreads = nthreads
-    och = 3 if stage else osrc.nch
+    och = 3 if stage else (nch or osrc.nch)
     out = np.zeros((j.row_end - j.row_begin, args.width, och), np.float32)
     rc = euo.lib().euo_render(C.byref(j), arr, len(srcs), euo.ptr(out), args.width * och)
     assert rc == 0, rc

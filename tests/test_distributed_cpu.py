@@ -1,0 +1,75 @@
+"""The N>1 host path on CPU: two gloo ranks broadcast a source container,
+render their row strips (with the oracle standing in for the GPU kernel - this
+is a test of the host logic, not of the kernel) and gather the frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_row_partition_covers_without_overlap():
+    from envutil_amd.distributed import row_partition
+    for h in (1, 7, 100, 24576, 24577):
+        for w in (1, 2, 3, 4, 8):
+            for align in (1, 4):
+                rows = [row_partition(h, w, r, align) for r in range(w)]
+                assert rows[0][0] == 0 and rows[-1][1] == h
+                for a, b in zip(rows, rows[1:]):
+                    assert a[1] == b[0] and a[0] <= a[1]
+                if align == 1:
+                    sizes = [b - a for a, b in rows]
+                    assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        row_partition(10, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import envutil_amd as ea
+    from envutil_amd.distributed import row_partition, broadcast_source, gather_strips
+    import euo
+    import jobs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        img = jobs.synth_image(128, 64, 3)
+        # rank 0 owns the prefiltered coefficients; rank 1 starts from garbage
+        o = jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img if rank == 0 else img * 0 + 7, 3)
+        flat = torch.from_numpy(o.container.reshape(-1))
+        broadcast_source(dist, flat, 0)             # in place: o.container now rank 0's
+        a = ea.arguments(ea.CUBEMAP, 32, 192, 90.0, spline_degree=3)
+        r0, r1 = row_partition(a.height, world, rank)
+        strip = torch.from_numpy(jobs.oracle_render(a, o, row_begin=r0, row_end=r1, nthreads=2))
+        frame = gather_strips(dist, strip, a.height, a.width, 3, rank, world)
+        if rank == 0:
+            whole = jobs.oracle_render(a, jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img, 3), nthreads=2)
+            q.put(bool((frame.numpy().view(np.uint32) == whole.view(np.uint32)).all()))
+        else:
+            q.put(frame is None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_render_gather_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [True, True]

@@ -254,3 +254,22 @@ def test_multi_facet_mixed_projections():
     os_, gs = facet_set(euo.RECTILINEAR, 64, 48, 50.0, 3, 3, seed=9)
     a = ea.arguments(ea.SPHERICAL, 256, 128, 360.0, spline_degree=3)
     assert_bits(ea.render(a, [g0] + gs[:3], 3), jobs.oracle_render(a, [o0] + os_[:3]), "mixed facets")
+
+
+# ---- channel adaption: repix_t ------------------------------------------------
+
+@pytest.mark.parametrize("src_n", [1, 2, 3, 4])
+@pytest.mark.parametrize("out_n", [1, 2, 3, 4])
+def test_repix_channel_adaption_bit_exact(src_n, out_n):
+    if src_n == out_n:
+        pytest.skip("no adaption")
+    img = jobs.synth_image(128, 64, src_n, seed=4)
+    if src_n in (2, 4):
+        # alpha with exact zeros (division by alpha is guarded in repix_t)
+        img[:, :, src_n - 1] = (np.indices((64, 128))[1] % 7 != 0).astype(np.float32)
+    o = jobs.OracleSource(euo.RECTILINEAR, 128, 64, 100.0, img, 1, brighten=1.3)
+    g = ea.Source.adopt(ea.facet_spec(ea.RECTILINEAR, 128, 64, 100.0, nchannels=src_n, brighten=1.3),
+                        o.container, 1, o.bc[0], o.bc[1])
+    for twine in (0, 2):
+        a = ea.arguments(ea.SPHERICAL, 150, 75, 360.0, yaw=20, spline_degree=1, twine=twine)
+        assert_bits(ea.render(a, g, out_n), jobs.oracle_render(a, o, nch=out_n), f"repix {src_n}->{out_n}")
