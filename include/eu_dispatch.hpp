@@ -1,0 +1,181 @@
+// eu_dispatch.hpp - C++ host mirror of the envutil surface this path plugs into.
+//
+// Same names and meaning as the reference (all in namespace project):
+//   projection_t                    envutil_basic.h:68-78
+//   extent_type / facet_base / facet_spec / arguments (the fields the render
+//   path reads)                     envutil_basic.h:432-705
+//   arguments::twine_setup          envutil_main.cc:1405-1616 (explicit twine)
+//   dispatch_base::payload(nchannels, ninputs, projection)
+//                                   envutil_dispatch.h:49-65
+//   get_dispatch()                  envutil_dispatch.h:70-73
+// Differences, all at the I/O edge (file I/O is out of scope): a facet carries
+// a pointer to its pixels instead of a file name, and the job's output goes to
+// a caller-provided float buffer instead of an image file. payload() returns 0
+// on success like the reference, or the negative eu_status of the C ABI
+// (the reference aborts instead).
+//
+// Header-only; link with -leu_hip.
+#ifndef EU_DISPATCH_HPP
+#define EU_DISPATCH_HPP
+
+#include <array>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+#include "eu_hip.h"
+
+namespace project {
+
+typedef enum { SPHERICAL, CYLINDRICAL, RECTILINEAR, STEREOGRAPHIC, FISHEYE, CUBEMAP, BIATAN6,
+               PRJ_NONE } projection_t;
+
+struct extent_type { double x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
+
+struct facet_base : public extent_type
+{
+  projection_t projection = SPHERICAL;
+  double hfov = 0.0;              // radians
+  double step = 0.0;
+  double yaw = 0.0, pitch = 0.0, roll = 0.0;   // radians
+  int width = 0, height = 0;
+  int window_width = 0, window_height = 0, window_x_offset = 0, window_y_offset = 0;
+  double shear_g = 0.0, shear_t = 0.0;
+  double s = 0.0, a = 0.0, b = 0.0, c = 0.0, d = 0.0, h = 0.0, v = 0.0;
+  bool has_shift = false, has_lcp = false, has_shear = false;
+
+  // facet_base::process_geometry, envutil_basic.h:499-521
+  void process_geometry()
+  {
+    double e[4];
+    eu_hip_get_extent(projection, width, height, hfov, e);
+    x0 = e[0]; x1 = e[1]; y0 = e[2]; y1 = e[3];
+    step = eu_hip_get_step(projection, width, height, hfov);
+    has_shift = (h != 0.0 || v != 0.0);
+    has_lcp = (a != 0.0 || b != 0.0 || c != 0.0);
+    has_shear = (shear_g != 0.0 || shear_t != 0.0);
+    double dv = std::fabs(y1 - y0) / 2.0, dh = std::fabs(x1 - x0) / 2.0;
+    s = (dh < dv) ? dh : dv;
+    if (window_width == 0) { window_width = width; window_height = height; }
+  }
+};
+
+struct facet_spec : public facet_base
+{
+  int facet_no = 0;
+  int nchannels = 3;
+  std::string asset_key;          // residency key (environment.h:84-227)
+  float brighten = 1.0f;
+  const float *pixels = nullptr;  // window_width x window_height x nchannels (cubemaps: 6 faces)
+};
+
+struct arguments : public facet_base
+{
+  int spline_degree = 1, prefilter_degree = -1;
+  int twine = 0;
+  float twine_width = 1.0f, twine_sigma = 0.0f, twine_threshold = 0.0f;
+  std::vector<std::array<float, 3>> twine_spread;
+  int support_min = 8, tile_size = 64;
+  int nchannels = 3;
+  int nfacets = 0;
+  std::vector<facet_spec> facet_spec_v;
+  float *p_output = nullptr;      // width x height x nchannels floats
+  bool verbose = false;
+
+  // target extent and step, envutil_main.cc:1203-1232
+  void target_setup()
+  {
+    double e[4];
+    eu_hip_get_extent(projection, width, height, hfov, e);
+    x0 = e[0]; x1 = e[1]; y0 = e[2]; y1 = e[3];
+    step = (x1 - x0) / width;
+    if (prefilter_degree < 0) prefilter_degree = spline_degree;
+    nfacets = int(facet_spec_v.size());
+  }
+
+  // make_spread for an explicitly given --twine (envutil_main.cc:1253-1355, :1585-1590)
+  void twine_setup()
+  {
+    twine_spread.clear();
+    if (twine <= 0) return;
+    std::vector<float> t(3 * size_t(twine < 2 ? 4 : twine * twine));
+    int n = eu_hip_make_spread(twine, twine, twine_width, twine_sigma, twine_threshold, t.data(),
+                               int(t.size() / 3));
+    for (int i = 0; i < n; i++) twine_spread.push_back({ t[3 * i], t[3 * i + 1], t[3 * i + 2] });
+  }
+};
+
+inline arguments args;            // the reference's global (envutil_basic.h:705)
+
+struct dispatch_base
+{
+  std::string hwy_target_name = "gfx950", hwy_target_str = "HIP/CDNA4";
+  virtual int payload(int nchannels, int ninputs, projection_t projection) const = 0;
+  virtual ~dispatch_base() {}
+};
+
+struct hip_dispatch : public dispatch_base
+{
+  mutable std::map<std::string, eu_source *> resident;   // asset_handler
+
+  static eu_facet to_eu(const facet_spec &f)
+  {
+    eu_facet e {};
+    e.projection = f.projection; e.nchannels = f.nchannels; e.hfov = f.hfov;
+    e.width = f.width; e.height = f.height;
+    e.window_width = f.window_width; e.window_height = f.window_height;
+    e.window_x_offset = f.window_x_offset; e.window_y_offset = f.window_y_offset;
+    e.yaw = f.yaw; e.pitch = f.pitch; e.roll = f.roll;
+    e.brighten = f.brighten; e.step = f.step; e.has_lcp = f.has_lcp;
+    e.a = f.a; e.b = f.b; e.c = f.c; e.h = f.h; e.v = f.v; e.s = f.s;
+    e.shear_g = f.shear_g; e.shear_t = f.shear_t;
+    return e;
+  }
+
+  int payload(int nchannels, int ninputs, projection_t projection) const override
+  {
+    if (projection != args.projection) return EU_ERR_ARGUMENT;
+    if ((ninputs == 9) != !args.twine_spread.empty()) return EU_ERR_ARGUMENT;
+    if (!args.p_output) return EU_ERR_ARGUMENT;
+    std::vector<eu_source *> srcs;
+    for (const auto &fct : args.facet_spec_v) {
+      auto it = resident.find(fct.asset_key);
+      if (it == resident.end()) {
+        eu_facet e = to_eu(fct);
+        eu_source *s = nullptr;
+        int rc = eu_hip_source_load(&e, fct.pixels, args.spline_degree, args.prefilter_degree,
+                                    args.support_min, args.tile_size, &s);
+        if (rc != EU_OK) return rc;
+        it = resident.emplace(fct.asset_key, s).first;
+      }
+      srcs.push_back(it->second);
+    }
+    eu_target t {};
+    t.projection = projection; t.width = args.width; t.height = args.height;
+    t.x0 = args.x0; t.x1 = args.x1; t.y0 = args.y0; t.y1 = args.y1;
+    t.yaw = args.yaw; t.pitch = args.pitch; t.roll = args.roll;
+    t.nchannels = nchannels;
+    t.ntaps = ninputs == 9 ? int(args.twine_spread.size()) : 0;
+    t.taps = ninputs == 9 ? args.twine_spread[0].data() : nullptr;
+    t.row_begin = 0; t.row_end = args.height; t.stage = 0;
+    return eu_hip_render(&t, srcs.data(), int(srcs.size()), args.p_output,
+                         size_t(args.width) * nchannels * sizeof(float), 0, nullptr);
+  }
+
+  // conclude_cycle / asset_handler.cycle (environment.h:202-227): drop everything
+  void clear() const
+  {
+    for (auto &kv : resident) eu_hip_source_release(kv.second);
+    resident.clear();
+  }
+  ~hip_dispatch() { clear(); }
+};
+
+inline const dispatch_base *get_dispatch()
+{
+  static hip_dispatch d;
+  return &d;
+}
+
+}  // namespace project
+#endif

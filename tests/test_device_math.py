@@ -17,14 +17,18 @@ def L():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hdr = os.path.join(ROOT, "envutil_amd", "csrc", "eu_math.h")
     if (not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(hdr))):
-        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC",
-                               "-shared", "-o", OUT, SRC, "-lm"])
+        # -mfma: eu_sinf/eu_cosf restate glibc's FMA-host variant with explicit fma()
+        fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
+        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC"]
+                              + fma + ["-shared", "-o", OUT, SRC, "-lm"])
     lib = C.CDLL(OUT)
     lib.check_atanf_range.restype = C.c_long
     lib.check_atanf_range.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
     lib.check_atan2f_random.restype = C.c_long
     lib.check_atan2f_random.argtypes = [C.c_long, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
     lib.check_atan2f_pairs.restype = C.c_long
+    lib.check_sincosf_range.restype = C.c_long
+    lib.check_sincosf_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     return lib
 
 
@@ -50,3 +54,12 @@ def test_atan2f_special_values(L):
     y = np.ascontiguousarray(pairs[:, 0])
     x = np.ascontiguousarray(pairs[:, 1])
     assert L.check_atan2f_pairs(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), len(y)) == 0
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_sinf_cosf_all_floats(L, which):
+    """glibc 2.35 sinf/cosf, FMA-host variant (s_sinf-fma.c): every bit pattern"""
+    if not L.have_sincosf():
+        pytest.skip("host CPU without FMA runs a different libm variant")
+    first_bad = C.c_uint32(0)
+    assert L.check_sincosf_range(0, 0xFFFFFFFF, which, C.byref(first_bad)) == 0, hex(first_bad.value)
