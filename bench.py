@@ -303,6 +303,7 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        cores = min(cores, 64)      # a 1-GPU box's fair share of a large host
         # probe, then size the band for about --cpu-seconds of work
         probe_rows = max(1, min(th // 6, (4 * cores)))
         mid = th // 12          # inside the first cube face / upper part of the frame
