@@ -117,6 +117,9 @@ __device__ __forceinline__ float eu_rand_safe(unsigned r, int emin, int emax)
 
 __global__ void eu_selftest_kernel(unsigned long long seed, int iters, unsigned long long *bad)
 {
+  __shared__ __attribute__((aligned(16))) float atab[EU_ATAN_TAB_FLOATS];
+  if (threadIdx.x < EU_ATAN_TAB_ENTRIES) eu_atan_tab_entry(threadIdx.x, atab + 8 * threadIdx.x);
+  __syncthreads();
   unsigned long long s = seed + 0x1000193ull * (blockIdx.x * blockDim.x + threadIdx.x);
   unsigned long long b_div = 0, b_sqrt = 0, b_atan2 = 0, b_cdiv = 0;
   const float c = 6.28318548202514648f, rc = 1.0f / c;
@@ -137,6 +140,11 @@ __global__ void eu_selftest_kernel(unsigned long long seed, int iters, unsigned 
     eu_f2 x = (i & 1) ? d : (eu_f2){ eu_rand_safe((unsigned)r1, -20, 3), eu_rand_safe((unsigned)(r1 >> 32), -20, 3) };
     eu_f2 t = eu_atan2f_2(y, x);
     b_atan2 += (eu_f2u(t.x) != eu_f2u(eu_atan2f(y.x, x.x))) + (eu_f2u(t.y) != eu_f2u(eu_atan2f(y.y, x.y)));
+    t = eu_atan2f_2_tab(y, x, atab, 0);
+    b_atan2 += (eu_f2u(t.x) != eu_f2u(eu_atan2f(y.x, x.x))) + (eu_f2u(t.y) != eu_f2u(eu_atan2f(y.y, x.y)));
+    eu_f2 xp = eu_abs2(x);
+    t = eu_atan2f_2_tab(y, xp, atab, 1);
+    b_atan2 += (eu_f2u(t.x) != eu_f2u(eu_atan2f(y.x, xp.x))) + (eu_f2u(t.y) != eu_f2u(eu_atan2f(y.y, xp.y)));
     eu_f2 v = { fabsf(eu_rand_safe((unsigned)r0, -30, 3)), fabsf(eu_rand_safe((unsigned)r1, -30, 3)) };
     eu_f2 cd = eu_div2_const(v, c, rc);
     b_cdiv += (eu_f2u(cd.x) != eu_f2u(v.x / c)) + (eu_f2u(cd.y) != eu_f2u(v.y / c));

@@ -180,4 +180,91 @@ EU_D2 eu_f2 eu_atan2f_2_xpos(eu_f2 y, eu_f2 x)
   return r;
 }
 
+// ---------------------------------------------------------------------------
+// Table-driven variant of eu_atanf_pos2. s_atanf.c's argument reduction is
+// x = num/den with (num, den) = (a*t + b, c*t + d) and a per-range (hi, lo):
+//   |t| < 7/16          : ( t      ,  1       )          a,b,c,d = 1, 0, 0, 1
+//   7/16 <= |t| < 11/16 : ( 2t - 1 ,  2 + t   )                    2,-1, 1, 2
+//   11/16 <= |t| < 19/16: ( t - 1  ,  t + 1   )                    1,-1, 1, 1
+//   19/16 <= |t| < 39/16: ( t - 1.5,  1 + 1.5t)                    1,-1.5,1.5,1
+//   39/16 <= |t|        : ( -1     ,  t       )                    0,-1, 1, 0
+// (a*t is exact for a in {0, 1, 2}; RN(RN(c*t) + d) is the reference's own
+// expression for every row). All range boundaries are multiples of 2^18 in the
+// float's bit pattern, so (bits >> 18) indexes an 81-entry table of
+// {a, b, c, d, hi, lo, 0, 0}; the selects of eu_atanf_pos2 become two 16-byte
+// reads (LDS on the device). Same bits as eu_atanf / glibc for every t >= 0.
+// ---------------------------------------------------------------------------
+#define EU_ATAN_TAB_ENTRIES 81
+#define EU_ATAN_TAB_FLOATS (EU_ATAN_TAB_ENTRIES * 8)
+
+EU_D2 void eu_atan_tab_entry(int idx, float *e)
+{
+  // idx = clamp((bits >> 18) - 0xfb7, 0, 80); boundaries 0x3ee00000, 0x3f300000,
+  // 0x3f980000, 0x401c0000 >> 18 = 0xfb8, 0xfcc, 0xfe6, 0x1007
+  int id = idx == 0 ? -1 : idx <= 20 ? 0 : idx <= 46 ? 1 : idx <= 79 ? 2 : 3;
+  const float A[5] = { 1.0f, 2.0f, 1.0f, 1.0f, 0.0f }, B[5] = { 0.0f, -1.0f, -1.0f, -1.5f, -1.0f };
+  const float Cc[5] = { 0.0f, 1.0f, 1.0f, 1.5f, 1.0f }, D[5] = { 1.0f, 2.0f, 1.0f, 1.0f, 0.0f };
+  const float HI[5] = { 0.0f, 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
+  const float LO[5] = { 0.0f, 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
+  int k = id + 1;
+  e[0] = A[k]; e[1] = B[k]; e[2] = Cc[k]; e[3] = D[k]; e[4] = HI[k]; e[5] = LO[k]; e[6] = 0.0f; e[7] = 0.0f;
+}
+
+EU_D2 eu_f2 eu_atanf_pos2_tab(eu_f2 t, const float *tab)
+{
+  const eu_u2 it = eu_bits2(t);
+  eu_i2 idx = (eu_i2)(it >> 18) - 0xfb7;
+  idx = __builtin_elementwise_min(__builtin_elementwise_max(idx, (eu_i2){ 0, 0 }), (eu_i2){ 80, 80 });
+  const float *e0 = tab + idx.x * 8, *e1 = tab + idx.y * 8;
+  const eu_f2 a = { e0[0], e1[0] }, b = { e0[1], e1[1] }, c = { e0[2], e1[2] }, d = { e0[3], e1[3] };
+  const eu_f2 hi = { e0[4], e1[4] }, lo = { e0[5], e1[5] };
+  const eu_i2 small = idx == 0, big = it >= 0x4c000000u;
+  eu_f2 num = a * t + b;
+  eu_f2 den = c * t + d;
+  eu_f2 x = eu_div2_safe(num, den);
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+              aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+              aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+              aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+  eu_f2 z = x * x;
+  eu_f2 w = z * z;
+  eu_f2 s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  eu_f2 s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  eu_f2 xs = x * (s1 + s2);
+  eu_f2 rsmall = x - xs;
+  eu_f2 rmid = hi - ((xs - lo) - x);
+  eu_f2 r = eu_sel2(small, rsmall, rmid);
+  const float hb = 1.5707962513e+00f + 7.5497894159e-08f;
+  return eu_sel2(big, (eu_f2){ hb, hb }, r);
+}
+
+// atan2f with the table; x_positive: the caller guarantees x > 0 or out of range
+EU_D2 eu_f2 eu_atan2f_2_tab(eu_f2 y, eu_f2 x, const float *tab, int x_positive)
+{
+  const eu_u2 hx = eu_bits2(x), hy = eu_bits2(y);
+  const eu_u2 ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+  const eu_i2 okx = ((x_positive ? hx : ix) - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 oky = (iy - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 ok = okx & oky;
+  // out-of-range lanes produce a value that is replaced below
+  eu_f2 q = eu_div2_safe(y, x);
+  eu_f2 z = eu_atanf_pos2_tab(eu_abs2(q), tab);
+  eu_f2 r;
+  if (x_positive) {
+    r = eu_float2(eu_bits2(z) ^ (hy & 0x80000000u));
+  } else {
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const eu_i2 xneg = (eu_i2)(hx >> 31) != 0, yneg = (eu_i2)(hy >> 31) != 0;
+    eu_f2 zl = z - pi_lo;
+    eu_f2 rpos = eu_float2(eu_bits2(z) ^ (hy & 0x80000000u));
+    eu_f2 rneg = eu_sel2(yneg, zl - pi, pi - zl);
+    r = eu_sel2(xneg, rneg, rpos);
+  }
+  if (__builtin_expect(!(ok.x & ok.y), 0)) {
+    if (!ok.x) r.x = eu_atan2f(y.x, x.x);
+    if (!ok.y) r.y = eu_atan2f(y.y, x.y);
+  }
+  return r;
+}
+
 #endif

@@ -193,7 +193,7 @@ __device__ __forceinline__ eu_f2 eu_div2_guarded(eu_f2 n, eu_f2 d)
 
 template <int PRJ>
 __device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r, eu_f2 &sx,
-                                           eu_f2 &sy)
+                                           eu_f2 &sy, const float *atab)
 {
   if constexpr (PRJ == EU_CUBEMAP || PRJ == EU_BIATAN6) {
     // ray_to_cubeface, geometry.h:1178-1289 (dominance classes by select)
@@ -211,7 +211,7 @@ __device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r
     if constexpr (PRJ == EU_BIATAN6) {
       // in_face = float(4/pi) * atan(in_face), environment.h:1480; atanf is odd
       const float k = (float)(4.0 / 3.14159265358979323846);
-      eu_f2 a0 = eu_atanf_pos2(eu_abs2(in0)), a1 = eu_atanf_pos2(eu_abs2(in1));
+      eu_f2 a0 = eu_atanf_pos2_tab(eu_abs2(in0), atab), a1 = eu_atanf_pos2_tab(eu_abs2(in1), atab);
       a0 = eu_float2(eu_bits2(a0) | (eu_bits2(in0) & 0x80000000u));
       a1 = eu_float2(eu_bits2(a1) | (eu_bits2(in1) & 0x80000000u));
       in0 = k * a0; in1 = k * a1;
@@ -230,15 +230,15 @@ __device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r
     {
       const eu_u2 iq = eu_bits2(q2);
       const eu_i2 ok = (iq - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
-      qs = eu_sqrt2_safe(eu_sel2(ok, q2, (eu_f2){ 1.0f, 1.0f }));
+      qs = eu_sqrt2_safe(q2);      // out-of-range lanes are replaced below
       if (__builtin_expect(!(ok.x & ok.y), 0)) {
         if (!ok.x) qs.x = sqrtf(q2.x);
         if (!ok.y) qs.y = sqrtf(q2.y);
       }
     }
     // s == 0 (ray along the vertical axis) fails the range check and takes the scalar path
-    eu_f2 lat = eu_atan2f_2_xpos(r.y, qs);
-    eu_f2 lon = eu_atan2f_2(r.x, r.z);
+    eu_f2 lat = eu_atan2f_2_tab(r.y, qs, atab, 1);
+    eu_f2 lon = eu_atan2f_2_tab(r.x, r.z, atab, 0);
     // a full-sphere image covers atan2f's whole range: every ray hits
     eu_i2 hit = { -1, -1 };
     if (!s.always_hit)
@@ -318,6 +318,12 @@ __device__ __forceinline__ void eu_eval2(const eu_src_dev &s, eu_f2 sx, eu_f2 sy
 template <int NCH, int DEG, int PRJ, bool TWINE>
 __global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params p)
 {
+  // atanf range table in LDS (eu_math2.h): filled before any thread leaves
+  __shared__ __attribute__((aligned(16))) float atab[EU_ATAN_TAB_FLOATS];
+  if constexpr (PRJ != EU_CUBEMAP) {
+    if (threadIdx.x < EU_ATAN_TAB_ENTRIES) eu_atan_tab_entry(threadIdx.x, atab + 8 * threadIdx.x);
+    __syncthreads();
+  }
   const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, p.unit_rows);
   if (b < 0) return;
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params 
   float pxa[NCH], pxb[NCH];
   if constexpr (!TWINE) {
     eu_f2 sx, sy;
-    const eu_i2 hit = eu_coord2<PRJ>(s, r00, sx, sy);
+    const eu_i2 hit = eu_coord2<PRJ>(s, r00, sx, sy, atab);
     eu_eval2<NCH, DEG>(s, sx, sy, hit, pxa, pxb);
   } else {
     // deriv_stepper (stepper.h:1591-1715) + twine_t::eval (twining.h:128-263)
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params 
       rk.y = r00.y + cx * dxy + cy * dyy;
       rk.z = r00.z + cx * dxz + cy * dyz;
       eu_f2 sx, sy;
-      const eu_i2 hit = eu_coord2<PRJ>(s, rk, sx, sy);
+      const eu_i2 hit = eu_coord2<PRJ>(s, rk, sx, sy, atab);
       float qa[NCH], qb[NCH];
       eu_eval2<NCH, DEG>(s, sx, sy, hit, qa, qb);
 #pragma unroll

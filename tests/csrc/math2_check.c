@@ -88,3 +88,63 @@ long check_atan2f_2_pairs(const float *y, const float *x, long n)
   }
   return bad;
 }
+
+/* table-driven variants (the ones the render kernel uses) */
+static float g_tab[EU_ATAN_TAB_FLOATS];
+static void fill_tab(void) { for (int i = 0; i < EU_ATAN_TAB_ENTRIES; i++) eu_atan_tab_entry(i, g_tab + 8 * i); }
+
+long check_atanf_pos2_tab_range(uint32_t first, uint32_t last)
+{
+  long bad = 0;
+  fill_tab();
+#pragma omp parallel for reduction(+:bad) schedule(static)
+  for (long long u = first; u <= (long long)last; u += 2) {
+    uint32_t a = (uint32_t)u, b = (uint32_t)(u + 1 <= last ? u + 1 : u);
+    float ta, tb;
+    memcpy(&ta, &a, 4); memcpy(&tb, &b, 4);
+    eu_f2 t = { ta, tb };
+    eu_f2 r = eu_atanf_pos2_tab(t, g_tab);
+    if (!same(r.x, atanf(ta))) bad++;
+    if (!same(r.y, atanf(tb))) bad++;
+  }
+  return bad;
+}
+
+long check_atan2f_2_tab_random(long n, uint64_t seed, int mode)
+{
+  long bad = 0;
+  fill_tab();
+#pragma omp parallel reduction(+:bad)
+  {
+    uint64_t s = seed;
+#ifdef _OPENMP
+    extern int omp_get_thread_num(void);
+    s += 0x7654321ull * (uint64_t)omp_get_thread_num();
+#endif
+#pragma omp for schedule(static)
+    for (long i = 0; i < n; i++) {
+      uint64_t r0 = mix(&s), r1 = mix(&s);
+      float v[4];
+      if (mode == 0) {
+        uint32_t w[4] = { (uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32) };
+        memcpy(v, w, 16);
+      } else {
+        v[0] = (float)((double)(uint32_t)r0 / 2147483648.0 - 1.0);
+        v[1] = (float)((double)(uint32_t)(r0 >> 32) / 2147483648.0 - 1.0);
+        v[2] = (float)((double)(uint32_t)r1 / 2147483648.0 - 1.0) * (mode == 2 ? 1e-4f : 6.0f);
+        v[3] = (float)((double)(uint32_t)(r1 >> 32) / 2147483648.0 - 1.0);
+      }
+      eu_f2 y = { v[0], v[2] }, x = { v[1], v[3] };
+      eu_f2 r = eu_atan2f_2_tab(y, x, g_tab, 0);
+      if (!same(r.x, atan2f(v[0], v[1]))) bad++;
+      if (!same(r.y, atan2f(v[2], v[3]))) bad++;
+      eu_f2 xp = { fabsf(v[1]), fabsf(v[3]) };
+      if (xp.x > 0.0f && xp.y > 0.0f && xp.x == xp.x && xp.y == xp.y) {
+        r = eu_atan2f_2_tab(y, xp, g_tab, 1);
+        if (!same(r.x, atan2f(v[0], xp.x))) bad++;
+        if (!same(r.y, atan2f(v[2], xp.y))) bad++;
+      }
+    }
+  }
+  return bad;
+}
