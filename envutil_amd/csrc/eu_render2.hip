@@ -49,17 +49,19 @@ __device__ __forceinline__ void eu_weights2(const float *wm, eu_f2 d, eu_f2 *w)
 }
 
 // weighted sum for one pixel: channels 0/1 packed, the rest scalar
-template <int NCH, int DEG>
-__device__ __forceinline__ void eu_accumulate1(const float *__restrict__ p0, long long es1,
+typedef const __attribute__((address_space(3))) float *eu_lptr;   // LDS address space: ds_read, not flat
+
+template <int NCH, int DEG, int TS = NCH, class STRIDE = long long, class PTR = const float *>
+__device__ __forceinline__ void eu_accumulate1(PTR p0, STRIDE es1,
                                                const float *wx, const float *wy, float tx,
                                                float ty, float *out)
 {
   if constexpr (DEG == 1) {
     float wl0 = 1.0f - tx, wr0 = tx, wl1 = 1.0f - ty, wr1 = ty;
-    const float *q = p0 + es1;
+    PTR q = p0 + es1;
     float a[NCH], b[NCH], c2[NCH], d[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) { a[c] = p0[c]; b[c] = p0[NCH + c]; c2[c] = q[c]; d[c] = q[NCH + c]; }
+    for (int c = 0; c < NCH; c++) { a[c] = p0[c]; b[c] = p0[TS + c]; c2[c] = q[c]; d[c] = q[TS + c]; }
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       float sum = a[c] * wl0;
@@ -75,12 +77,12 @@ __device__ __forceinline__ void eu_accumulate1(const float *__restrict__ p0, lon
     float sum[NCH];
 #pragma unroll
     for (int j = 0; j < order; j++) {
-      const float *rowp = p0 + j * es1;
+      PTR rowp = p0 + j * es1;
       float t[order][NCH];
 #pragma unroll
       for (int i = 0; i < order; i++)
 #pragma unroll
-        for (int c = 0; c < NCH; c++) t[i][c] = rowp[i * NCH + c];
+        for (int c = 0; c < NCH; c++) t[i][c] = rowp[i * TS + c];
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         float r = t[0][c] * wx[0];
@@ -291,10 +293,11 @@ __device__ __forceinline__ void eu_eval2(const eu_src_dev &s, eu_f2 sx, eu_f2 sy
     else { wxa[i] = wxb[i] = wya[i] = wyb[i] = 0.0f; }
   }
   // a missed lane's coordinate is arbitrary (the reference evaluates it at an
-  // uninitialised but gated position and zeroes the result): keep its address
-  // inside the container
-  const int ixa = hit.x ? (int)fx.x : 0, iya = hit.x ? (int)fy.x : 0;
-  const int ixb = hit.y ? (int)fx.y : 0, iyb = hit.y ? (int)fy.y : 0;
+  // uninitialised but gated position and zeroes the result)
+  // a lane without a hit reads the window at the core origin (always inside
+  // the container, framed or not); its result is discarded
+  const int ixa = hit.x ? (int)fx.x : DEG / 2, iya = hit.x ? (int)fy.x : DEG / 2;
+  const int ixb = hit.y ? (int)fx.y : DEG / 2, iyb = hit.y ? (int)fy.y : DEG / 2;
   const float *pa = s.base + (long long)(ixa - DEG / 2) * NCH + (long long)(iya - DEG / 2) * s.es1;
   const float *pb = s.base + (long long)(ixb - DEG / 2) * NCH + (long long)(iyb - DEG / 2) * s.es1;
   eu_accumulate1<NCH, DEG>(pa, s.es1, wxa, wya, tx.x, ty.x, pxa);
@@ -379,9 +382,199 @@ __global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params 
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-staged variant (no twining): 32x16 output tiles, still two pixels per
+// lane (rows y and y+8 of one column), so that the tile's source footprint is a
+// compact box for ANY orientation of the mapping (polar cube faces, rotated
+// targets). The box is copied into LDS once with coalesced row reads - every
+// source texel passes the texture addresser once per tile instead of once per
+// tap - and the (d+1)^2 taps are 16-byte LDS reads. Tiles whose box exceeds the
+// LDS budget (pole of a lat/lon source, the +-180 degree seam, strong
+// minification) gather from global memory like eu_render2_kernel; the choice is
+// per workgroup.
+// ---------------------------------------------------------------------------
+
+#define EU3_TW 32
+#define EU3_TH 16
+#define EU3_LDS_BYTES (36 * 1024)
+
+__device__ __forceinline__ int eu_wmin(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int eu_wmax(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int NCH, int DEG, int PRJ>
+__global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_params p)
+{
+  constexpr int TEX = NCH == 3 ? 4 : NCH;              // floats per LDS texel
+  constexpr int CAP = EU3_LDS_BYTES / (TEX * 4);       // texels
+  __shared__ __attribute__((aligned(16))) float tile[CAP * TEX];
+  __shared__ __attribute__((aligned(16))) float atab[EU_ATAN_TAB_FLOATS];
+  __shared__ int bbw[4][4];
+  if constexpr (PRJ != EU_CUBEMAP) {
+    if (threadIdx.x < EU_ATAN_TAB_ENTRIES) eu_atan_tab_entry(threadIdx.x, atab + 8 * threadIdx.x);
+  }
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, p.unit_rows);
+  if (b < 0) return;                                   // whole workgroup
+  __syncthreads();
+  const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = tile_x * EU3_TW + (threadIdx.x & 31);
+  const int ya = p.row_begin + tile_y * EU3_TH + (threadIdx.x >> 5), yb = ya + 8;
+  const bool la = x < p.width && ya < p.row_end, lb = x < p.width && yb < p.row_end;
+  const int xc = x < p.width ? x : p.width - 1;
+  const int yac = ya < p.row_end ? ya : p.row_end - 1, ybc = yb < p.row_end ? yb : p.row_end - 1;
+  const eu_src_dev &s = p.src;
+
+  // rays: the two pixels share the column value and differ in the row constants
+  eu_ray2 r;
+  {
+    const float *ra = p.row + (long long)yac * EU_ROW_FLOATS, *rb = p.row + (long long)ybc * EU_ROW_FLOATS;
+    const float c0 = p.col[xc];
+    const eu_f2 A0 = { ra[0], rb[0] }, A1 = { ra[1], rb[1] }, A2 = { ra[2], rb[2] };
+    const eu_f2 B0 = { ra[3], rb[3] }, B1 = { ra[4], rb[4] }, B2 = { ra[5], rb[5] };
+    if (p.form == EU_FORM_BCA) {
+      const float c1 = p.col[p.width + xc];
+      const eu_f2 C0 = { ra[6], rb[6] }, C1 = { ra[7], rb[7] }, C2 = { ra[8], rb[8] };
+      r.x = B0 * c0 + C0 * c1 + A0;
+      r.y = B1 * c0 + C1 * c1 + A1;
+      r.z = B2 * c0 + C2 * c1 + A2;
+    } else {
+      r.x = B0 * c0 + A0;
+      r.y = B1 * c0 + A1;
+      r.z = B2 * c0 + A2;
+    }
+  }
+  eu_f2 sx, sy;
+  eu_i2 hit = eu_coord2<PRJ>(s, r, sx, sy, atab);
+  hit = hit & (eu_i2){ la ? -1 : 0, lb ? -1 : 0 };
+
+  // gate + split
+  eu_f2 gx = eu_gate2(sx, s.gate0, s.lower0, s.upper0);
+  eu_f2 gy = eu_gate2(sy, s.gate1, s.lower1, s.upper1);
+  eu_f2 fx, fy;
+  if constexpr (DEG & 1) {
+    fx = (eu_f2){ floorf(gx.x), floorf(gx.y) }; fy = (eu_f2){ floorf(gy.x), floorf(gy.y) };
+  } else {
+    fx = (eu_f2){ roundf(gx.x), roundf(gx.y) }; fy = (eu_f2){ roundf(gy.x), roundf(gy.y) };
+  }
+  const eu_f2 tx = gx - fx, ty = gy - fy;
+  // lanes without a hit (misses, pixels outside the frame) use the window at
+  // the core origin: inside every container, framed or not
+  const int ixa = hit.x ? (int)fx.x : DEG / 2, iya = hit.x ? (int)fy.x : DEG / 2;
+  const int ixb = hit.y ? (int)fx.y : DEG / 2, iyb = hit.y ? (int)fy.y : DEG / 2;
+
+  // bounding box of the base positions of all hitting pixels of the tile
+  int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+  if (hit.x) { mnx = ixa; mxx = ixa; mny = iya; mxy = iya; }
+  if (hit.y) { mnx = min(mnx, ixb); mxx = max(mxx, ixb); mny = min(mny, iyb); mxy = max(mxy, iyb); }
+  mnx = eu_wmin(mnx); mny = eu_wmin(mny); mxx = eu_wmax(mxx); mxy = eu_wmax(mxy);
+  if (lane == 0) { bbw[wave][0] = mnx; bbw[wave][1] = mny; bbw[wave][2] = mxx; bbw[wave][3] = mxy; }
+  __syncthreads();
+  mnx = min(min(bbw[0][0], bbw[1][0]), min(bbw[2][0], bbw[3][0]));
+  mny = min(min(bbw[0][1], bbw[1][1]), min(bbw[2][1], bbw[3][1]));
+  mxx = max(max(bbw[0][2], bbw[1][2]), max(bbw[2][2], bbw[3][2]));
+  mxy = max(max(bbw[0][3], bbw[1][3]), max(bbw[2][3], bbw[3][3]));
+  mnx = __builtin_amdgcn_readfirstlane(mnx); mny = __builtin_amdgcn_readfirstlane(mny);
+  mxx = __builtin_amdgcn_readfirstlane(mxx); mxy = __builtin_amdgcn_readfirstlane(mxy);
+  const bool any = mnx != INT_MAX;
+  const int bx0 = mnx - DEG / 2, by0 = mny - DEG / 2;
+  const long long bw = (long long)mxx - mnx + DEG + 1, bh = (long long)mxy - mny + DEG + 1;
+  const bool fits = any && bw * bh <= CAP;
+
+  constexpr int order = DEG + 1;
+  eu_f2 wx[order], wy[order];
+  if constexpr (DEG >= 2) {
+    eu_weights2<DEG>(s.wm, tx, wx);
+    eu_weights2<DEG>(s.wm, ty, wy);
+  }
+  float wxa[order], wxb[order], wya[order], wyb[order];
+#pragma unroll
+  for (int i = 0; i < order; i++) {
+    if constexpr (DEG >= 2) { wxa[i] = wx[i].x; wxb[i] = wx[i].y; wya[i] = wy[i].x; wyb[i] = wy[i].y; }
+    else { wxa[i] = wxb[i] = wya[i] = wyb[i] = 0.0f; }
+  }
+
+  float pxa[NCH], pxb[NCH];
+  if (fits) {
+    const int ibw = (int)bw, ibh = (int)bh;
+    // stage the box: wave w copies rows w, w+4, ...; lanes run along x
+    for (int rr = wave; rr < ibh; rr += 4) {
+      const float *g = s.base + (long long)(by0 + rr) * s.es1 + (long long)bx0 * NCH;
+      for (int c = lane; c < ibw; c += 64) {
+        const float *q = g + (long long)c * NCH;
+        float *d = tile + (rr * ibw + c) * TEX;
+        if constexpr (NCH == 3) {
+          float v0 = q[0], v1 = q[1], v2 = q[2];
+          *reinterpret_cast<float4 *>(d) = make_float4(v0, v1, v2, 0.0f);
+        } else if constexpr (NCH == 4) {
+          *reinterpret_cast<float4 *>(d) = *reinterpret_cast<const float4 *>(q);
+        } else if constexpr (NCH == 2) {
+          *reinterpret_cast<float2 *>(d) = *reinterpret_cast<const float2 *>(q);
+        } else {
+          d[0] = q[0];
+        }
+      }
+    }
+    __syncthreads();
+    const int pitch = ibw * TEX;
+    // lanes without a hit read the box origin (their result is discarded)
+    const int oa = hit.x ? ((iya - mny) * ibw + (ixa - mnx)) * TEX : 0;
+    const int ob = hit.y ? ((iyb - mny) * ibw + (ixb - mnx)) * TEX : 0;
+    eu_lptr lt = (eu_lptr)tile;
+    eu_accumulate1<NCH, DEG, TEX, int, eu_lptr>(lt + oa, pitch, wxa, wya, tx.x, ty.x, pxa);
+    eu_accumulate1<NCH, DEG, TEX, int, eu_lptr>(lt + ob, pitch, wxb, wyb, tx.y, ty.y, pxb);
+  } else {
+    const float *pa = s.base + (long long)(ixa - DEG / 2) * NCH + (long long)(iya - DEG / 2) * s.es1;
+    const float *pb = s.base + (long long)(ixb - DEG / 2) * NCH + (long long)(iyb - DEG / 2) * s.es1;
+    eu_accumulate1<NCH, DEG>(pa, s.es1, wxa, wya, tx.x, ty.x, pxa);
+    eu_accumulate1<NCH, DEG>(pb, s.es1, wxb, wyb, tx.y, ty.y, pxb);
+  }
+  constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
+  const bool bright = s.brighten != 1.0f;
+  if (la) {
+    float *o = p.out + (long long)(ya - p.row_begin) * p.out_stride + (long long)x * NCH;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float v = pxa[c];
+      if (bright && c < ncol) v = v * s.brighten;
+      o[c] = hit.x ? v : 0.0f;
+    }
+  }
+  if (lb) {
+    float *o = p.out + (long long)(yb - p.row_begin) * p.out_stride + (long long)x * NCH;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float v = pxb[c];
+      if (bright && c < ncol) v = v * s.brighten;
+      o[c] = hit.y ? v : 0.0f;
+    }
+  }
+}
+
 template <int NCH, int DEG, int PRJ>
 static int launch2_ndp(const eu_render_params &p, hipStream_t st)
 {
+  static const int use_lds = [] { const char *e = getenv("EU_HIP_LDS"); return e ? atoi(e) : 1; }();
+  if (!p.twine && use_lds && p.norm_mode == EU_NORM_NONE) {
+    eu_render_params q = p;
+    q.tiles_x = (p.width + EU3_TW - 1) / EU3_TW;
+    q.tiles_y = (p.row_end - p.row_begin + EU3_TH - 1) / EU3_TH;
+    static const int unit3 = [] { const char *e = getenv("EU_HIP_UNIT3"); return e ? atoi(e) : 2; }();
+    q.unit_rows = unit3 > 0 ? unit3 : 2;
+    dim3 grid3((unsigned)eu_xcd_grid(q.tiles_x, q.tiles_y, q.unit_rows)), block3(256);
+    hipLaunchKernelGGL((eu_render3_kernel<NCH, DEG, PRJ>), grid3, block3, 0, st, q);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, p.unit_rows)), block(256);
   if (p.twine) hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, false>), grid, block, 0, st, p);
