@@ -48,6 +48,22 @@ __device__ __forceinline__ void eu_weights2(const float *wm, eu_f2 d, eu_f2 *w)
   }
 }
 
+// LDS texel read: one aligned 16-byte ds_read_b128 for RGB(X) / RGBA texels
+template <int NCH, int TS, class PTR>
+__device__ __forceinline__ void eu_texel(PTR q, float *t)
+{
+  if constexpr (TS == 4 && sizeof(PTR) == 4) {
+    typedef float eu_f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) eu_f4 *eu_l4ptr;
+    eu_f4 v = *(eu_l4ptr)q;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z;
+    if constexpr (NCH == 4) t[3] = v.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) t[c] = q[c];
+  }
+}
+
 // weighted sum for one pixel: channels 0/1 packed, the rest scalar
 typedef const __attribute__((address_space(3))) float *eu_lptr;   // LDS address space: ds_read, not flat
 
@@ -60,8 +76,8 @@ __device__ __forceinline__ void eu_accumulate1(PTR p0, STRIDE es1,
     float wl0 = 1.0f - tx, wr0 = tx, wl1 = 1.0f - ty, wr1 = ty;
     PTR q = p0 + es1;
     float a[NCH], b[NCH], c2[NCH], d[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) { a[c] = p0[c]; b[c] = p0[TS + c]; c2[c] = q[c]; d[c] = q[TS + c]; }
+    eu_texel<NCH, TS, PTR>(p0, a); eu_texel<NCH, TS, PTR>(p0 + TS, b);
+    eu_texel<NCH, TS, PTR>(q, c2); eu_texel<NCH, TS, PTR>(q + TS, d);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       float sum = a[c] * wl0;
@@ -80,9 +96,7 @@ __device__ __forceinline__ void eu_accumulate1(PTR p0, STRIDE es1,
       PTR rowp = p0 + j * es1;
       float t[order][NCH];
 #pragma unroll
-      for (int i = 0; i < order; i++)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) t[i][c] = rowp[i * TS + c];
+      for (int i = 0; i < order; i++) eu_texel<NCH, TS, PTR>(rowp + i * TS, t[i]);
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         float r = t[0][c] * wx[0];
@@ -411,11 +425,11 @@ __device__ __forceinline__ int eu_wmax(int v)
   return v;
 }
 
-template <int NCH, int DEG, int PRJ>
+template <int NCH, int DEG, int PRJ, bool STAGE>
 __global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_params p)
 {
   constexpr int TEX = NCH == 3 ? 4 : NCH;              // floats per LDS texel
-  constexpr int CAP = EU3_LDS_BYTES / (TEX * 4);       // texels
+  constexpr int CAP = STAGE ? EU3_LDS_BYTES / (TEX * 4) : 4;   // texels
   __shared__ __attribute__((aligned(16))) float tile[CAP * TEX];
   __shared__ __attribute__((aligned(16))) float atab[EU_ATAN_TAB_FLOATS];
   __shared__ int bbw[4][4];
@@ -474,7 +488,11 @@ __global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_para
   const int ixb = hit.y ? (int)fx.y : DEG / 2, iyb = hit.y ? (int)fy.y : DEG / 2;
 
   // bounding box of the base positions of all hitting pixels of the tile
+  bool fits = false;
   int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+  int bx0 = 0, by0 = 0;
+  long long bw = 0, bh = 0;
+  if constexpr (STAGE) {
   if (hit.x) { mnx = ixa; mxx = ixa; mny = iya; mxy = iya; }
   if (hit.y) { mnx = min(mnx, ixb); mxx = max(mxx, ixb); mny = min(mny, iyb); mxy = max(mxy, iyb); }
   mnx = eu_wmin(mnx); mny = eu_wmin(mny); mxx = eu_wmax(mxx); mxy = eu_wmax(mxy);
@@ -487,9 +505,10 @@ __global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_para
   mnx = __builtin_amdgcn_readfirstlane(mnx); mny = __builtin_amdgcn_readfirstlane(mny);
   mxx = __builtin_amdgcn_readfirstlane(mxx); mxy = __builtin_amdgcn_readfirstlane(mxy);
   const bool any = mnx != INT_MAX;
-  const int bx0 = mnx - DEG / 2, by0 = mny - DEG / 2;
-  const long long bw = (long long)mxx - mnx + DEG + 1, bh = (long long)mxy - mny + DEG + 1;
-  const bool fits = any && bw * bh <= CAP;
+  bx0 = mnx - DEG / 2; by0 = mny - DEG / 2;
+  bw = (long long)mxx - mnx + DEG + 1; bh = (long long)mxy - mny + DEG + 1;
+  fits = any && bw * bh <= CAP;
+  }
 
   constexpr int order = DEG + 1;
   eu_f2 wx[order], wy[order];
@@ -564,7 +583,9 @@ __global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_para
 template <int NCH, int DEG, int PRJ>
 static int launch2_ndp(const eu_render_params &p, hipStream_t st)
 {
-  static const int use_lds = [] { const char *e = getenv("EU_HIP_LDS"); return e ? atoi(e) : 1; }();
+  // EU_HIP_LDS: 0 = row-strip tiles (eu_render2_kernel), 1 = 32x16 tiles staged
+  // through LDS, 2 = 32x16 tiles with direct gathers
+  static const int use_lds = [] { const char *e = getenv("EU_HIP_LDS"); return e ? atoi(e) : 0; }();
   if (!p.twine && use_lds && p.norm_mode == EU_NORM_NONE) {
     eu_render_params q = p;
     q.tiles_x = (p.width + EU3_TW - 1) / EU3_TW;
@@ -572,7 +593,8 @@ static int launch2_ndp(const eu_render_params &p, hipStream_t st)
     static const int unit3 = [] { const char *e = getenv("EU_HIP_UNIT3"); return e ? atoi(e) : 2; }();
     q.unit_rows = unit3 > 0 ? unit3 : 2;
     dim3 grid3((unsigned)eu_xcd_grid(q.tiles_x, q.tiles_y, q.unit_rows)), block3(256);
-    hipLaunchKernelGGL((eu_render3_kernel<NCH, DEG, PRJ>), grid3, block3, 0, st, q);
+    if (use_lds == 1) hipLaunchKernelGGL((eu_render3_kernel<NCH, DEG, PRJ, true>), grid3, block3, 0, st, q);
+    else hipLaunchKernelGGL((eu_render3_kernel<NCH, DEG, PRJ, false>), grid3, block3, 0, st, q);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, p.unit_rows)), block(256);

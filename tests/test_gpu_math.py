@@ -53,3 +53,53 @@ def test_packed_kernel_partial_sphere_misses():
     got, ref = ea.render(a, g), jobs.oracle_render(a, o)
     assert (jobs.bits(got) == jobs.bits(ref)).all()
     assert (ref == 0).all(axis=2).any() and (ref != 0).any()
+
+
+def test_device_pointer_as_torch_tensor():
+    """bench.py's multi-GPU path broadcasts straight into the library's device
+    buffer through a torch view of the raw pointer (__cuda_array_interface__):
+    the view must alias the container"""
+    import torch
+    import bench
+    img = jobs.synth_image(64, 32, 3)
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 64, 32, 360.0), img, 3)
+    ptr, n = src.device_ptr()
+    t = torch.as_tensor(bench._DevBuf(ptr, n), device=torch.device("cuda:0"))
+    host = src.download().reshape(-1)
+    assert t.numel() == host.size and np.array_equal(t.cpu().numpy(), host)
+    # a write through the view is what a broadcast does
+    t.mul_(2.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(src.download().reshape(-1), host * 2.0)
+
+
+@pytest.mark.parametrize("tw,th", [(1, 1), (3, 2), (17, 5), (513, 3), (64, 1), (65, 4), (129, 9)])
+def test_ragged_target_sizes(tw, th):
+    """targets narrower than a vector, a tile, a segment; odd leftovers"""
+    img = jobs.synth_image(128, 64, 3)
+    o = jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img, 3)
+    g = ea.Source.adopt(ea.facet_spec(ea.SPHERICAL, 128, 64, 360.0), o.container, 3, o.bc[0], o.bc[1])
+    for twine in (0, 2):
+        a = ea.arguments(ea.RECTILINEAR, tw, th, 80.0, yaw=15, pitch=-8, roll=3, spline_degree=3, twine=twine)
+        got, ref = ea.render(a, g), jobs.oracle_render(a, o)
+        assert (jobs.bits(got) == jobs.bits(ref)).all(), (tw, th, twine)
+    # the same through the general kernel and the 2-D tile kernels
+    a = ea.arguments(ea.SPHERICAL, tw, th, 360.0, spline_degree=3)
+    ref = jobs.oracle_render(a, o)
+    assert (jobs.bits(ea.render(a, g)) == jobs.bits(ref)).all()
+
+
+def test_error_codes_not_aborts():
+    img = jobs.synth_image(64, 32, 3)
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 64, 32, 360.0), img, 1)
+    # stereographic target: not built -> EU_ERR_UNSUPPORTED, the process lives
+    a = ea.arguments(ea.STEREOGRAPHIC, 32, 32, 100.0, spline_degree=1)
+    with pytest.raises(ea.EuError, match="-3"):
+        ea.render(a, src)
+    # cubemap target that is not 1:6
+    a = ea.arguments(ea.CUBEMAP, 32, 100, 90.0, spline_degree=1)
+    with pytest.raises(ea.EuError, match="-2"):
+        ea.render(a, src)
+    # and the library still works afterwards
+    a = ea.arguments(ea.SPHERICAL, 32, 16, 360.0, spline_degree=1)
+    assert ea.render(a, src).shape == (16, 32, 3)
