@@ -64,6 +64,30 @@ def build(force=False):
 _lib = None
 
 
+def _share_hip_runtime():
+    """A PyTorch-ROCm wheel carries its own libamdhip64 / libhsa-runtime64, and a
+    process that ends up with two HIP runtimes sees no GPU in the second one.
+    When torch is installed, load its runtime first (without importing torch):
+    libeu_hip.so's NEEDED libamdhip64.so.7 then binds to the same copy, whichever
+    of the two is imported first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -72,6 +96,7 @@ def lib():
     if not os.path.exists(p):
         raise EuError(f"{p} is missing: run envutil_amd.build() (hipcc, gfx950). "
                       "There is no fallback implementation.")
+    _share_hip_runtime()
     L = C.CDLL(p)
     vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
     L.eu_hip_last_error.restype = C.c_char_p
