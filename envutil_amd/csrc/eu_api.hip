@@ -258,7 +258,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   if (key != g.plan_key) {
     eu::stepper_tables tb;
     if (!eu::build_stepper_tables(*t, basis, twine, twine, tb))
-      return fail(EU_ERR_UNSUPPORTED, "fisheye/stereographic target steppers not built yet");
+      return fail(EU_ERR_UNSUPPORTED, "no stepper for this target projection");
     if ((rc = grow(&g.col, &g.col_cap, tb.col.size()))) return rc;
     if ((rc = grow(&g.row, &g.row_cap, tb.row.size()))) return rc;
     HIPCHK(hipMemcpyAsync(g.col, tb.col.data(), tb.col.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
@@ -339,7 +339,7 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
       eu::mat3 r_fct = eu::make_r3(srcs[f]->fct.roll, srcs[f]->fct.pitch, srcs[f]->fct.yaw, true);
       eu::mat3 basis = eu::rotate(r_cam, r_fct);
       if (!eu::build_stepper_tables(*t, basis, true, twine, tb))
-        return fail(EU_ERR_UNSUPPORTED, "stereographic target stepper not built yet");
+        return fail(EU_ERR_UNSUPPORTED, "no stepper for this target projection");
       rows.insert(rows.end(), tb.row.begin(), tb.row.end());
     }
     if ((rc = grow(&g.mcol, &g.mcol_cap, tb.col.size()))) return rc;

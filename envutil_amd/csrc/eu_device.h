@@ -12,7 +12,8 @@
 // (stepper.h) hoisted into tables that the host fills once per target.
 enum { EU_FORM_BCA = 0,      // (B*c0 + C*c1) + A   spherical, cylindrical
        EU_FORM_BA = 1,       //  B*c0 + A           rectilinear, cubemap, biatan6
-       EU_FORM_FISH = 2 };   //  per-pixel polar form of the fisheye stepper
+       EU_FORM_FISH = 2,     //  per-pixel polar form of the fisheye stepper
+       EU_FORM_STER = 3 };   //  the same with the stereographic latitude
                              //  (c0 = planar x, row: xx, yy, zz, planar y)
 enum { EU_NORM_NONE = 0, EU_NORM_DIV = 1, EU_NORM_CYL = 2 };
 

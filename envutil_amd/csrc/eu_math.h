@@ -230,4 +230,53 @@ EU_HD float eu_sinf(float y) { return eu_sincosf_impl(y, 0); }
 EU_HD float eu_cosf(float y) { return eu_sincosf_impl(y, 1); }
 #endif
 
+// ---------------------------------------------------------------------------
+// stereographic_stepper::work (stepper.h:1146): a = M_PI_2 - 2.0 * atan(norm / 2.0)
+// is formed in double (libm's double atan) and narrows to float before sincos.
+// glibc's double atan (IBM accurate library, table driven) is not restated;
+// instead the fdlibm double algorithm below (error < 1 ulp of double) is used and
+// the NARROWED float result is compared with the live libm for every float
+// norm >= 0 (tests/test_device_math.py::test_stereographic_angle_all_floats):
+// the map float -> float is identical on all 2^31 inputs, which is what parity
+// needs. IEEE double add/mul/div only, no contraction.
+// ---------------------------------------------------------------------------
+EU_HD double eu_atan_pos_d(double x)
+{
+  const double atanhi[4] = { 4.63647609000806093515e-01, 7.85398163397448278999e-01,
+                             9.82793723247329054082e-01, 1.57079632679489655800e+00 };
+  const double atanlo[4] = { 2.26987774529616870924e-17, 3.06161699786838301793e-17,
+                             1.39033110312309984516e-17, 6.12323399573676603587e-17 };
+  const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01,
+               aT2 = 1.42857142725034663711e-01, aT3 = -1.11111104054623557880e-01,
+               aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+               aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
+               aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
+               aT10 = 1.62858201153657823623e-02;
+  int id;
+  if (!(x < 7.378697629483821e+19)) {       // x >= 2^66 or NaN
+    if (x != x) return x + x;
+    return atanhi[3] + atanlo[3];
+  }
+  if (x < 0.4375) {
+    if (x < 7.450580596923828e-09) return x; // 2^-27
+    id = -1;
+  } else if (x < 1.1875) {
+    if (x < 0.6875) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); }
+    else            { id = 1; x = (x - 1.0) / (x + 1.0); }
+  } else {
+    if (x < 2.4375) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); }
+    else            { id = 3; x = -1.0 / x; }
+  }
+  const double z = x * x, w = z * z;
+  const double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  const double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  if (id < 0) return x - x * (s1 + s2);
+  return atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+}
+
+EU_HD float eu_ster_angle(float nrm)
+{
+  return (float)(1.57079632679489661923 - 2.0 * eu_atan_pos_d((double)nrm / 2.0));
+}
+
 #endif

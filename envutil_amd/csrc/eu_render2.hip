@@ -630,7 +630,7 @@ static int launch2_n(const eu_render_params &p, hipStream_t st)
 extern "C" int eu_launch_render2(const eu_render_params *pp, void *stream)
 {
   eu_render_params p = *pp;
-  if (p.stage != 0 || p.form == EU_FORM_FISH || p.src.has_lcp || p.nch_out != p.nch) return 1;
+  if (p.stage != 0 || p.form >= EU_FORM_FISH || p.src.has_lcp || p.nch_out != p.nch) return 1;
   if (p.src.prj != EU_SPHERICAL && p.src.prj != EU_CUBEMAP && p.src.prj != EU_BIATAN6) return 1;
   if (p.src.degree < 1 || p.src.degree > 3 || p.src.es0 != p.nch) return 1;
   static const int unit_rows = [] { const char *e = getenv("EU_HIP_UNIT"); return e ? atoi(e) : EU2_UNIT_ROWS; }();

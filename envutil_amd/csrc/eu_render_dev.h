@@ -450,7 +450,7 @@ __device__ __forceinline__ void eu_ray(int form, const float *rowt, float c0, fl
                                        float &rx, float &ry, float &rz)
 {
   // rowt: A[3], B[3], C[3]
-  if (form == EU_FORM_FISH) {
+  if (form == EU_FORM_FISH || form == EU_FORM_STER) {
     // fisheye_stepper::work, stepper.h:1019-1030: a = M_PI_2 - norm(planar) is
     // formed in double and narrows to float before sin/cos (the float sincos
     // overload is the one that binds)
@@ -458,7 +458,10 @@ __device__ __forceinline__ void eu_ray(int form, const float *rowt, float c0, fl
     float sqn = p0 * p0;
     sqn = sqn + p1 * p1;
     const float nrm = sqrtf(sqn);
-    const float a = (float)(1.57079632679489661923 - (double)nrm);
+    // stereographic_stepper::work, stepper.h:1146: a = M_PI_2 - 2.0 * atan(norm / 2.0),
+    // double atan, see eu_ster_angle
+    const float a = form == EU_FORM_STER ? eu_ster_angle(nrm)
+                                         : (float)(1.57079632679489661923 - (double)nrm);
     const float bb = eu_atan2f(p0, p1);
     const float z = eu_sinf(a), r = eu_cosf(a), sx = eu_sinf(bb), sy = eu_cosf(bb);
     rx = rowt[0] * r * sx + rowt[6] * z + rowt[3] * r * sy;

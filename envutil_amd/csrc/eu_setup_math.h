@@ -359,8 +359,7 @@ inline float planar_row(int H, float b0, float b1, float bias, int y)
 
 // Fills the tables for one target. `normalize` is the stepper template flag:
 // false for single-facet rendering without twining, true otherwise
-// (envutil_payload.cc:2118, :2227). Returns false for projections whose
-// stepper needs per-pixel transcendentals (fisheye, stereographic).
+// (envutil_payload.cc:2118, :2227). Returns false for an unknown projection.
 inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool normalize,
                                  bool twine, stepper_tables &tb)
 {
@@ -408,16 +407,18 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
       }
       break;
     case EU_FISHEYE:
-      // fisheye_stepper::work (stepper.h:1019-1030) has no per-row or per-column
-      // invariant beyond the planar coordinates themselves
-      tb.form = EU_FORM_FISH;
+    case EU_STEREOGRAPHIC:
+      // fisheye_stepper::work (stepper.h:1019-1030) and stereographic_stepper::work
+      // (:1146-1157) have no per-row or per-column invariant beyond the planar
+      // coordinates themselves
+      tb.form = prj == EU_FISHEYE ? EU_FORM_FISH : EU_FORM_STER;
       for (int x = 0; x < W; x++) {
         tb.col[x] = p0[x];
         if (twine) tb.col[(size_t)2 * W + x] = p0b[x];
       }
       break;
     default:
-      return false;   // stereographic: needs libm's double atan on the device
+      return false;
   }
   for (int y = 0; y < H; y++) {
     for (int v = 0; v < (twine ? 2 : 1); v++) {
@@ -437,6 +438,7 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
           for (int i = 0; i < 3; i++) { r[3 + i] = xx[i]; r[i] = yy[i] * p1 + zz[i]; }
           break;
         case EU_FISHEYE:
+        case EU_STEREOGRAPHIC:
           for (int i = 0; i < 3; i++) { r[i] = xx[i]; r[3 + i] = yy[i]; r[6 + i] = zz[i]; }
           break;
         default: {               // cubemap, biatan6: stepper.h:1274-1358, :1449-1560

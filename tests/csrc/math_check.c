@@ -105,3 +105,25 @@ int have_sincosf(void) { return 1; }
 #else
 int have_sincosf(void) { return 0; }
 #endif
+
+/* stereographic stepper angle (stepper.h:1146) for every float norm in
+ * [first, last] (bit patterns of non-negative floats) against the live libm */
+long check_ster_angle_range(uint32_t first, uint32_t last, uint32_t *first_bad)
+{
+  long bad = 0;
+  uint32_t fb = 0;
+#pragma omp parallel for reduction(+:bad) schedule(static)
+  for (long long u = first; u <= (long long)last; u++) {
+    float x;
+    uint32_t uu = (uint32_t)u;
+    memcpy(&x, &uu, 4);
+    float ref = (float)(M_PI_2 - 2.0 * atan((double)x / 2.0));
+    if (!same(eu_ster_angle(x), ref)) {
+      bad++;
+#pragma omp critical
+      if (!fb) fb = uu;
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return bad;
+}

@@ -63,3 +63,12 @@ def test_sinf_cosf_all_floats(L, which):
         pytest.skip("host CPU without FMA runs a different libm variant")
     first_bad = C.c_uint32(0)
     assert L.check_sincosf_range(0, 0xFFFFFFFF, which, C.byref(first_bad)) == 0, hex(first_bad.value)
+
+
+def test_stereographic_angle_all_floats(L):
+    """(float)(M_PI_2 - 2.0 * atan(norm / 2.0)) with libm's double atan
+    (stepper.h:1146) against the device restatement, every norm >= 0 incl. inf"""
+    L.check_ster_angle_range.restype = C.c_long
+    L.check_ster_angle_range.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+    first_bad = C.c_uint32(0)
+    assert L.check_ster_angle_range(0, 0x7F800000, C.byref(first_bad)) == 0, hex(first_bad.value)

@@ -51,6 +51,7 @@ TARGETS = [
     (ea.BIATAN6, 24, 144, 90.0),
     (ea.SPHERICAL, 1100, 12, 360.0),      # segments of 512 + leftover lanes
     (ea.FISHEYE, 120, 90, 200.0),         # per-pixel sinf/cosf/atan2f on the device
+    (ea.STEREOGRAPHIC, 110, 84, 240.0),   # ... plus the double atan of stepper.h:1146
 ]
 
 
@@ -273,3 +274,13 @@ def test_repix_channel_adaption_bit_exact(src_n, out_n):
     for twine in (0, 2):
         a = ea.arguments(ea.SPHERICAL, 150, 75, 360.0, yaw=20, spline_degree=1, twine=twine)
         assert_bits(ea.render(a, g, out_n), jobs.oracle_render(a, o, nch=out_n), f"repix {src_n}->{out_n}")
+
+
+@pytest.mark.parametrize("tprj,tw,th,thfov", TARGETS[6:8])
+@pytest.mark.parametrize("twine", [0, 3])
+def test_pixels_polar_targets(latlon, tprj, tw, th, thfov, twine):
+    """fisheye / stereographic targets (per-pixel transcendental steppers), all
+    the way to pixels, single source and twined"""
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 3)
+    a = ea.arguments(tprj, tw, th, thfov, yaw=70, pitch=-25, roll=11, spline_degree=3, twine=twine)
+    assert_bits(ea.render(a, g), jobs.oracle_render(a, o), f"pixels prj {tprj} twine {twine}")
