@@ -57,7 +57,7 @@ def build(force=False):
     """compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)"""
     if force:
         subprocess.check_call(["make", "-s", "-C", HERE, "clean"])
-    subprocess.check_call(["make", "-s", "-j4", "-C", HERE])
+    subprocess.check_call(["make", "-s", "-j8", "-C", HERE])
     return lib_path()
 
 

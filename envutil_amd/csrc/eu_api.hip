@@ -311,8 +311,6 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   const eu_source *s0 = srcs[0];
   for (int f = 0; f < nsrc; f++) {
     if (!srcs[f]) return fail(EU_ERR_HANDLE, "null source");
-    if (srcs[f]->nch != t->nchannels)
-      return fail(EU_ERR_UNSUPPORTED, "channel adaption (repix_t) not built yet: target and source channel counts differ");
     if (srcs[f]->degree != s0->degree) return fail(EU_ERR_ARGUMENT, "facets must share the spline degree");
   }
   const bool twine = t->ntaps > 0;

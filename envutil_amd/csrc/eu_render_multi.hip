@@ -63,6 +63,18 @@ __device__ __forceinline__ void eu_syn_ray(const eu_multi_params &p, int f, cons
   }
 }
 
+#ifdef EU_MULTI_NCH
+// the facet's environment with channel adaption; a real call (one body per
+// source channel count and degree, shared by all kernels of this file)
+template <int SN, int DEG>
+__device__ __noinline__ float4 eu_env_adapted(const eu_src_dev *s, int out_n, float rx, float ry,
+                                              float rz)
+{
+  float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+  eu_environment_repix<SN, DEG>(*s, out_n, rx, ry, rz, t);
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+
 // evaluate facet `want` (wave-divergent, -1: none) for this lane
 template <int NCH, int DEG>
 __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want, const eu_pix &px,
@@ -79,7 +91,23 @@ __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want
     if (pending == f) {
       float rx, ry, rz;
       eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
-      eu_environment<NCH, DEG>(p.srcs[f], rx, ry, rz, out);
+      const eu_src_dev &s = p.srcs[f];
+      if (s.nch == NCH) {
+        eu_environment<NCH, DEG>(s, rx, ry, rz, out);
+      } else {
+        // a facet with another channel count: repix_t inside its environment
+        // object (environment.h:1846-1900); f is wave-uniform, so is this switch
+        float4 t;
+        switch (s.nch) {
+          case 1: t = eu_env_adapted<1, DEG>(&s, NCH, rx, ry, rz); break;
+          case 2: t = eu_env_adapted<2, DEG>(&s, NCH, rx, ry, rz); break;
+          case 3: t = eu_env_adapted<3, DEG>(&s, NCH, rx, ry, rz); break;
+          default: t = eu_env_adapted<4, DEG>(&s, NCH, rx, ry, rz); break;
+        }
+        const float tt[4] = { t.x, t.y, t.z, t.w };
+#pragma unroll
+        for (int c = 0; c < NCH; c++) out[c] = tt[c];
+      }
       pending = -1;
     }
   }
@@ -232,6 +260,26 @@ static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+#endif  // EU_MULTI_NCH
+
+#define EU_CAT2(a, b) a##b
+#define EU_CAT(a, b) EU_CAT2(a, b)
+
+#ifdef EU_MULTI_NCH
+// this translation unit carries the kernels of ONE channel count (the Makefile
+// compiles the file four times, so that the four compile in parallel)
+extern "C" int EU_CAT(eu_launch_render_multi_nch, EU_MULTI_NCH)(const eu_multi_params *p, int degree,
+                                                               void *stream)
+{
+  constexpr bool plus = EU_MULTI_NCH == 2 || EU_MULTI_NCH == 4;
+  return launch_multi_n<EU_MULTI_NCH, plus>(*p, degree, (hipStream_t)stream);
+}
+#else
+extern "C" int eu_launch_render_multi_nch1(const eu_multi_params *p, int degree, void *stream);
+extern "C" int eu_launch_render_multi_nch2(const eu_multi_params *p, int degree, void *stream);
+extern "C" int eu_launch_render_multi_nch3(const eu_multi_params *p, int degree, void *stream);
+extern "C" int eu_launch_render_multi_nch4(const eu_multi_params *p, int degree, void *stream);
+
 extern "C" int eu_launch_render_multi(const void *pp, int degree, void *stream)
 {
   eu_multi_params p = *(const eu_multi_params *)pp;
@@ -239,12 +287,12 @@ extern "C" int eu_launch_render_multi(const void *pp, int degree, void *stream)
   p.tiles_x = (p.width + EU_TILE_W - 1) / EU_TILE_W;
   p.tiles_y = (p.row_end - p.row_begin + EU_TILE_H - 1) / EU_TILE_H;
   if (p.tiles_x <= 0 || p.tiles_y <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   switch (p.nch) {
-    case 1: return launch_multi_n<1, false>(p, degree, st);
-    case 3: return launch_multi_n<3, false>(p, degree, st);
-    case 2: return launch_multi_n<2, true>(p, degree, st);
-    case 4: return launch_multi_n<4, true>(p, degree, st);
+    case 1: return eu_launch_render_multi_nch1(&p, degree, stream);
+    case 2: return eu_launch_render_multi_nch2(&p, degree, stream);
+    case 3: return eu_launch_render_multi_nch3(&p, degree, stream);
+    case 4: return eu_launch_render_multi_nch4(&p, degree, stream);
   }
   return -2;
 }
+#endif

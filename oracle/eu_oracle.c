@@ -1457,8 +1457,7 @@ static void synopsis_group(const syn_t *sy, float rays[][EUO_LANES][3], int n, f
       }
       for (int c = 0; c < nch; c++) px[l][c] = 0.0f;
       if (champ >= 0) {
-        mount_eval(&sy->mnt[champ], rays[champ][l], px[l], NULL);
-        brighten_px(&sy->mnt[champ], px[l]);
+        env_eval(&sy->mnt[champ], rays[champ][l], nch, px[l], NULL);
       }
     }
     return;
@@ -1507,8 +1506,7 @@ static void synopsis_group(const syn_t *sy, float rays[][EUO_LANES][3], int n, f
     float help[EUO_LANES][4];
     int opaque = 1;
     for (int l = 0; l < n; l++) {
-      mount_eval(&sy->mnt[next_best], rays[next_best][l], help[l], NULL);
-      brighten_px(&sy->mnt[next_best], help[l]);
+      env_eval(&sy->mnt[next_best], rays[next_best][l], nch, help[l], NULL);
       if (!(help[l][nch - 1] >= 1.0f)) opaque = 0;
     }
     if (opaque) {
@@ -1518,8 +1516,7 @@ static void synopsis_group(const syn_t *sy, float rays[][EUO_LANES][3], int n, f
   }
   for (int f = 0; f < nf; f++)
     for (int l = 0; l < n; l++) {
-      mount_eval(&sy->mnt[f], rays[f][l], lv[f][l], NULL);
-      brighten_px(&sy->mnt[f], lv[f][l]);
+      env_eval(&sy->mnt[f], rays[f][l], nch, lv[f][l], NULL);
     }
   for (int i = 0; i < layers; i++)
     for (int l = 0; l < n; l++) {
@@ -1542,7 +1539,8 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
   double r_cam[9];
   euo_make_r3(job->roll, job->pitch, job->yaw, 0, r_cam);
   for (int f = 0; f < nsrc; f++) {
-    if (srcs[f].spl.nch != nch) { free(sy); free(st); return -3; }
+    /* a facet with another channel count goes through repix_t inside its
+     * environment object (environment.h:1846-1900) */
     double r_fct[9], basis[9];
     euo_make_r3(srcs[f].roll, srcs[f].pitch, srcs[f].yaw, 1, r_fct);
     euo_rotate_r3(r_cam, r_fct, basis);

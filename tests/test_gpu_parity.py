@@ -257,6 +257,21 @@ def test_multi_facet_mixed_projections():
     assert_bits(ea.render(a, [g0] + gs[:3], 3), jobs.oracle_render(a, [o0] + os_[:3]), "mixed facets")
 
 
+@pytest.mark.parametrize("mix,out_n", [((3, 4), 4), ((1, 3), 3), ((2, 4, 1, 3), 4), ((4, 3), 3),
+                                       ((3, 1), 1), ((4, 2), 2)])
+@pytest.mark.parametrize("twine", [0, 2])
+def test_multi_facet_mixed_channel_counts(mix, out_n, twine):
+    """facets with different channel counts in one job: each facet's environment
+    adapts through repix_t (environment.h:1846-1900); the job runs at the
+    largest count (envutil_main.cc:1003-1157) or any other the caller asks for"""
+    sets = {n: facet_set(euo.RECTILINEAR, 72, 72, 95.0, n, 1, seed=21) for n in set(mix)}
+    os_ = [sets[mix[i % len(mix)]][0][i] for i in range(6)]
+    gs = [sets[mix[i % len(mix)]][1][i] for i in range(6)]
+    a = ea.arguments(ea.SPHERICAL, 180, 90, 360.0, yaw=20, pitch=-6, roll=3, spline_degree=1,
+                     twine=twine)
+    assert_bits(ea.render(a, gs, out_n), jobs.oracle_render(a, os_, nch=out_n), f"mixed channels {mix}->{out_n}")
+
+
 # ---- channel adaption: repix_t ------------------------------------------------
 
 @pytest.mark.parametrize("src_n", [1, 2, 3, 4])
