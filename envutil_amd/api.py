@@ -46,7 +46,13 @@ class Target(C.Structure):
                 ("yaw", C.c_double), ("pitch", C.c_double), ("roll", C.c_double),
                 ("nchannels", C.c_int32), ("ntaps", C.c_int32),
                 ("taps", C.POINTER(C.c_float)),
-                ("row_begin", C.c_int32), ("row_end", C.c_int32), ("stage", C.c_int32)]
+                ("row_begin", C.c_int32), ("row_end", C.c_int32), ("stage", C.c_int32),
+                ("crop_x0", C.c_int32), ("crop_y0", C.c_int32),
+                ("crop_w", C.c_int32), ("crop_h", C.c_int32),
+                ("out_format", C.c_int32)]
+
+
+OUT_FLOAT, OUT_SRGBA8 = 0, 1
 
 
 def lib_path():
@@ -280,7 +286,14 @@ class arguments:
 
     def __init__(self, projection, width, height, hfov, yaw=0.0, pitch=0.0, roll=0.0,
                  spline_degree=1, prefilter_degree=None, twine=0, twine_width=1.0,
-                 twine_sigma=0.0, twine_threshold=0.0, support_min=8, tile_size=64):
+                 twine_sigma=0.0, twine_threshold=0.0, support_min=8, tile_size=64,
+                 crop=None, tethered=False):
+        # store_cropped + p_crop_x0/x1/y0/y1 (envutil_basic.h:684-687) as
+        # (x0, x1, y0, y1); tethered: the job writes packed sRGBA8 words
+        # (args.p_screen_data, envutil_payload.cc:524-530)
+        self.store_cropped = crop is not None
+        self.p_crop = tuple(crop) if crop is not None else None
+        self.tethered = tethered
         self.projection = projection
         self.width, self.height = width, height
         self.hfov = hfov
@@ -310,26 +323,46 @@ class arguments:
         if self.twine_spread is not None:
             t.ntaps = len(self.twine_spread)
             t.taps = self.twine_spread.ctypes.data_as(C.POINTER(C.c_float))
+        if self.store_cropped:
+            x0, x1, y0, y1 = self.p_crop
+            t.crop_x0, t.crop_y0, t.crop_w, t.crop_h = x0, y0, x1 - x0, y1 - y0
+        t.out_format = OUT_SRGBA8 if self.tethered else OUT_FLOAT
         t.row_begin = row_begin
-        t.row_end = self.height if row_end is None else row_end
+        t.row_end = self.out_height if row_end is None else row_end
         t.stage = stage
         return t
+
+    @property
+    def out_width(self):
+        return self.p_crop[1] - self.p_crop[0] if self.store_cropped else self.width
+
+    @property
+    def out_height(self):
+        return self.p_crop[3] - self.p_crop[2] if self.store_cropped else self.height
 
 
 def render(args, sources, nchannels=None, row_begin=0, row_end=None, stage=0, out=None):
     """zimt::process(shape, get, act, put, bill) for rows [row_begin, row_end):
-    returns (rows, width, nch) float32 on the host."""
+    returns (rows, width, nch) float32 on the host - (rows, width) uint32
+    sRGBA8 words for a tethered job; width/rows are those of the crop window
+    when args.store_cropped."""
     if not isinstance(sources, (list, tuple)):
         sources = [sources]
     nch = nchannels or sources[0].fct.nchannels
     t = args.target(nch, row_begin, row_end, stage)
-    och = 3 if stage else nch
     rows = t.row_end - t.row_begin
-    if out is None:
-        out = np.zeros((rows, args.width, och), np.float32)
+    w = args.out_width
+    if args.tethered:
+        och = 1
+        if out is None:
+            out = np.zeros((rows, w), np.uint32)
+    else:
+        och = 3 if stage else nch
+        if out is None:
+            out = np.zeros((rows, w, och), np.float32)
     arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
-    _check(lib().eu_hip_render(C.byref(t), arr, len(sources), _ptr(out),
-                               args.width * och * 4, 0, None))
+    _check(lib().eu_hip_render(C.byref(t), arr, len(sources), out.ctypes.data_as(C.c_void_p),
+                               w * och * 4, 0, None))
     return out
 
 
@@ -343,8 +376,9 @@ def render_timed(args, sources, out_dev_ptr, iters, nchannels=None, row_begin=0,
     t = args.target(nch, row_begin, row_end, 0)
     arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
     ms = C.c_float()
+    och = 1 if args.tethered else nch
     _check(lib().eu_hip_render_timed(C.byref(t), arr, len(sources), C.c_void_p(out_dev_ptr),
-                                     args.width * nch * 4, iters, C.byref(ms)))
+                                     args.out_width * och * 4, iters, C.byref(ms)))
     return ms.value
 
 

@@ -49,6 +49,7 @@ struct context {
   hipStream_t stream = nullptr;
   float *col = nullptr, *row = nullptr, *taps = nullptr;
   size_t col_cap = 0, row_cap = 0, taps_cap = 0;
+  float *lut = nullptr;        // to_screen_t's sRGB LUT, 257 floats
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
   // the tables of the last target stay valid while (target geometry,
   // orientation, taps) repeat: streaming / tethered jobs re-render the same
@@ -81,6 +82,12 @@ int ensure_init()
   if (lr) dev = atoi(lr) % n;
   HIPCHK(hipSetDevice(dev));
   HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  {
+    float lut[257];
+    eu::screen_lut(lut);
+    HIPCHK(hipMalloc((void **)&g.lut, sizeof lut));
+    HIPCHK(hipMemcpy(g.lut, lut, sizeof lut, hipMemcpyHostToDevice));
+  }
   g.device = dev;
   return EU_OK;
 }
@@ -219,6 +226,31 @@ void source_bcs(const eu_facet *f, int *bc0, int *bc1)
     *bc0 = EU_BC_PERIODIC;
 }
 
+// the processed frame: the whole target or its crop window (store_cropped)
+inline int frame_w(const eu_target *t) { return t->crop_w > 0 ? t->crop_w : t->width; }
+inline int frame_h(const eu_target *t) { return t->crop_w > 0 ? t->crop_h : t->height; }
+
+int check_target(const eu_target *t)
+{
+  if (t->nchannels < 1 || t->nchannels > 4) return fail(EU_ERR_ARGUMENT, "target channels must be 1..4");
+  if (t->width <= 0 || t->height <= 0) return fail(EU_ERR_ARGUMENT, "empty target");
+  if (t->crop_w < 0 || (t->crop_w > 0 && (t->crop_h <= 0 || t->crop_x0 < 0 || t->crop_y0 < 0 ||
+                        (long long)t->crop_x0 + t->crop_w > t->width ||
+                        (long long)t->crop_y0 + t->crop_h > t->height)))
+    return fail(EU_ERR_ARGUMENT, "crop window outside the target");
+  if (t->row_begin < 0 || t->row_end > frame_h(t) || t->row_begin > t->row_end)
+    return fail(EU_ERR_ARGUMENT, "row range outside the target");
+  if (t->ntaps < 0 || t->ntaps > EU_MAX_TAPS || (t->ntaps > 0 && !t->taps))
+    return fail(EU_ERR_ARGUMENT, "bad twining tap table");
+  if ((t->projection == EU_CUBEMAP || t->projection == EU_BIATAN6) && t->height != 6 * t->width)
+    return fail(EU_ERR_ARGUMENT, "cubemap targets are 1:6");
+  if (t->out_format != EU_OUT_FLOAT && t->out_format != EU_OUT_SRGBA8)
+    return fail(EU_ERR_ARGUMENT, "unknown output format");
+  if (t->out_format == EU_OUT_SRGBA8 && t->stage)
+    return fail(EU_ERR_ARGUMENT, "stage outputs are float only");
+  return EU_OK;
+}
+
 int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *out_dev,
                  size_t row_stride_bytes, eu_render_params *p)
 {
@@ -227,14 +259,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     return fail(EU_ERR_UNSUPPORTED, "multi-facet synopsis (voronoi_syn) not built yet: nsrc must be 1");
   const eu_source *s = srcs[0];
   if (!s) return fail(EU_ERR_HANDLE, "null source");
-  if (t->nchannels < 1 || t->nchannels > 4) return fail(EU_ERR_ARGUMENT, "target channels must be 1..4");
-  if (t->width <= 0 || t->height <= 0) return fail(EU_ERR_ARGUMENT, "empty target");
-  if (t->row_begin < 0 || t->row_end > t->height || t->row_begin > t->row_end)
-    return fail(EU_ERR_ARGUMENT, "row range outside the target");
-  if (t->ntaps < 0 || t->ntaps > EU_MAX_TAPS || (t->ntaps > 0 && !t->taps))
-    return fail(EU_ERR_ARGUMENT, "bad twining tap table");
-  if ((t->projection == EU_CUBEMAP || t->projection == EU_BIATAN6) && t->height != 6 * t->width)
-    return fail(EU_ERR_ARGUMENT, "cubemap targets are 1:6");
+  { int rc0 = check_target(t); if (rc0) return rc0; }
   if (row_stride_bytes % sizeof(float))
     return fail(EU_ERR_ARGUMENT, "row stride must be a multiple of 4 bytes");
   const bool twine = t->ntaps > 0;
@@ -246,7 +271,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   std::vector<unsigned char> key(sizeof(eu_target) + 3 * sizeof(double) + 3 * sizeof(float) * (size_t)t->ntaps);
   {
     eu_target tk = *t;
-    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0;
+    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
     unsigned char *q = key.data();
     memcpy(q, &tk, sizeof tk); q += sizeof tk;
     double fo[3] = { s->fct.yaw, s->fct.pitch, s->fct.roll };
@@ -278,8 +303,9 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     g.plan_key.swap(key);
   }
   memset(p, 0, sizeof *p);
-  p->width = t->width; p->height = t->height;
+  p->width = frame_w(t); p->height = frame_h(t);
   p->row_begin = t->row_begin; p->row_end = t->row_end;
+  p->lut = t->out_format == EU_OUT_SRGBA8 ? g.lut : nullptr;
   p->form = form; p->norm_mode = norm_mode;
   p->twine = twine; p->ntaps = t->ntaps; p->stage = t->stage; p->nch = s->nch;
   p->nch_out = t->nchannels;
@@ -300,6 +326,7 @@ struct multi_params {
   float *out;
   long long out_stride;
   int tiles_x, tiles_y;
+  const float *lut;
 };
 
 // fuse() for several facets (envutil_payload.cc:2139-2180, :2240-2281): one
@@ -308,6 +335,7 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
                 size_t row_stride_bytes, multi_params *p, int *degree)
 {
   if (nsrc > 16) return fail(EU_ERR_UNSUPPORTED, "more than 16 facets per job not built yet");
+  { int rc0 = check_target(t); if (rc0) return rc0; }
   const eu_source *s0 = srcs[0];
   for (int f = 0; f < nsrc; f++) {
     if (!srcs[f]) return fail(EU_ERR_HANDLE, "null source");
@@ -318,7 +346,7 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
                                  + 3 * sizeof(float) * (size_t)t->ntaps + sizeof(int));
   {
     eu_target tk = *t;
-    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0;
+    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
     unsigned char *q = key.data();
     memcpy(q, &tk, sizeof tk); q += sizeof tk;
     memcpy(q, &nsrc, sizeof(int)); q += sizeof(int);
@@ -366,7 +394,8 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   HIPCHK(hipMemcpyAsync(g.msrc, sd.data(), sizeof(eu_src_dev) * (size_t)nsrc, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
   memset(p, 0, sizeof *p);
-  p->width = t->width; p->height = t->height; p->row_begin = t->row_begin; p->row_end = t->row_end;
+  p->width = frame_w(t); p->height = frame_h(t); p->row_begin = t->row_begin; p->row_end = t->row_end;
+  p->lut = t->out_format == EU_OUT_SRGBA8 ? g.lut : nullptr;
   p->form = g.mplan_form; p->norm_mode = g.mplan_norm; p->twine = twine; p->ntaps = t->ntaps;
   p->nch = t->nchannels; p->nfct = nsrc; p->plus = (t->nchannels == 2 || t->nchannels == 4);
   p->col = g.mcol; p->row = g.mrow; p->taps = g.mtaps; p->srcs = g.msrc;
@@ -574,16 +603,16 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   int rc;
   if ((rc = ensure_init())) return rc;
   if (!trg) return fail(EU_ERR_ARGUMENT, "null target");
-  const int och = trg->stage ? 3 : trg->nchannels;
-  const size_t min_stride = (size_t)trg->width * och * sizeof(float);
+  // words per pixel: a packed sRGBA8 word, 3 floats of a stage output, or the channels
+  const int och = trg->out_format == EU_OUT_SRGBA8 ? 1 : trg->stage ? 3 : trg->nchannels;
+  const size_t min_stride = (size_t)frame_w(trg) * och * sizeof(float);
   if (out_row_stride_bytes < min_stride) return fail(EU_ERR_ARGUMENT, "row stride smaller than a row");
   eu_render_params p;
   multi_params mp;
   int mdeg = 0;
   hipStream_t st = stream ? (hipStream_t)stream : g.stream;
   if (!srcs || nsrc < 1) return fail(EU_ERR_ARGUMENT, "no source");
-  if (trg->row_begin < 0 || trg->row_end > trg->height || trg->row_begin > trg->row_end)
-    return fail(EU_ERR_ARGUMENT, "row range outside the target");
+  if ((rc = check_target(trg))) return rc;
   const bool multi = nsrc > 1;
   if (multi && trg->stage) return fail(EU_ERR_ARGUMENT, "stage outputs exist for single-facet jobs only");
   if (out_on_device) {
@@ -598,7 +627,7 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   }
   const size_t rows = (size_t)(trg->row_end - trg->row_begin);
   if (!rows) return EU_OK;
-  if ((rc = grow(&g.stage, &g.stage_cap, rows * trg->width * och))) return rc;
+  if ((rc = grow(&g.stage, &g.stage_cap, rows * frame_w(trg) * och))) return rc;
   if (multi) {
     if ((rc = build_multi(trg, srcs, nsrc, g.stage, min_stride, &mp, &mdeg))) return rc;
     if (eu_launch_render_multi(&mp, mdeg, st)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");

@@ -63,6 +63,7 @@ struct eu_render_params {
   int tiles_x, tiles_y;      // grid of 64x4 tiles
   int unit_rows;             // tile rows per XCD unit (eu_render2.hip)
   int direct;                // 1: never stage through LDS (A/B switch, EU_HIP_DIRECT=1)
+  const float *lut;          // to_screen_t LUT (257 floats): packed sRGBA8 words; null: floats
   eu_src_dev src;
 };
 

@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
         for (int c = 0; c < on; c++) acc[c] = acc[c] + cw * q4[c];
       }
     }
+    if (p.lut) {
+      reinterpret_cast<unsigned *>(dst)[x] = eu_to_screen(p.lut, on, acc);
+      return;
+    }
     float *o4 = dst + (long long)x * on;
     for (int c = 0; c < on; c++) o4[c] = acc[c];
     return;
@@ -114,9 +118,7 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
       for (int c = 0; c < NCH; c++) px[c] = px[c] + cw * q[c];
     }
   }
-  float *o = dst + (long long)x * NCH;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) o[c] = px[c];
+  eu_put<NCH>(dst, p.lut, x, px);
 }
 
 // ---------------------------------------------------------------------------
@@ -233,9 +235,7 @@ __global__ __launch_bounds__(256) void eu_render_lds_kernel(const eu_render_para
 #pragma unroll
     for (int c = 0; c < ncol; c++) px[c] = px[c] * p.src.brighten;
   }
-  float *o = p.out + (long long)(y - p.row_begin) * p.out_stride + (long long)x * NCH;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) o[c] = px[c];
+  eu_put<NCH>(p.out + (long long)(y - p.row_begin) * p.out_stride, p.lut, x, px);
 }
 
 // ---------------------------------------------------------------------------

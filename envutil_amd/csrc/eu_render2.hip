@@ -388,12 +388,8 @@ __global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params 
   }
 
   float *o = p.out + (long long)(y - p.row_begin) * p.out_stride;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) o[(long long)xa * NCH + c] = pxa[c];
-  if (vb) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) o[(long long)xb * NCH + c] = pxb[c];
-  }
+  eu_put<NCH>(o, p.lut, xa, pxa);
+  if (vb) eu_put<NCH>(o, p.lut, xb, pxb);
 }
 
 // ---------------------------------------------------------------------------
@@ -586,7 +582,7 @@ static int launch2_ndp(const eu_render_params &p, hipStream_t st)
   // EU_HIP_LDS: 0 = row-strip tiles (eu_render2_kernel), 1 = 32x16 tiles staged
   // through LDS, 2 = 32x16 tiles with direct gathers
   static const int use_lds = [] { const char *e = getenv("EU_HIP_LDS"); return e ? atoi(e) : 0; }();
-  if (!p.twine && use_lds && p.norm_mode == EU_NORM_NONE) {
+  if (!p.twine && use_lds && !p.lut && p.norm_mode == EU_NORM_NONE) {
     eu_render_params q = p;
     q.tiles_x = (p.width + EU3_TW - 1) / EU3_TW;
     q.tiles_y = (p.row_end - p.row_begin + EU3_TH - 1) / EU3_TH;

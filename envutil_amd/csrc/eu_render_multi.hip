@@ -30,6 +30,7 @@ struct eu_multi_params {
   float *out;
   long long out_stride;
   int tiles_x, tiles_y;
+  const float *lut;          // to_screen_t LUT or null (eu_put)
 };
 
 struct eu_pix { int x, y; };
@@ -241,9 +242,7 @@ __global__ __launch_bounds__(256) void eu_render_multi_kernel(const eu_multi_par
     }
   }
   if (!live) return;
-  float *o = p.out + (long long)(px.y - p.row_begin) * p.out_stride + (long long)px.x * NCH;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) o[c] = out[c];
+  eu_put<NCH>(p.out + (long long)(px.y - p.row_begin) * p.out_stride, p.lut, px.x, out);
 }
 
 template <int NCH, bool PLUS>

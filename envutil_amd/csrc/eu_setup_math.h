@@ -331,17 +331,22 @@ struct stepper_tables {
 
 // planar x of every column, with the accumulation the reference performs:
 // segment-start value of the pixel's lane plus k additions of delta
-inline void planar_columns(int W, float a0, float a1, float bias, float *out)
+// W: width of the frame; the OW columns written start at discrete coordinate
+// x_off (bill.get_offset, wielding.h:215-224): segments of 512 count from the
+// first PROCESSED column, the offset is added to the coordinate init() receives
+inline void planar_columns(int W, float a0, float a1, float bias, float *out, int x_off = 0,
+                           int OW = -1)
 {
+  if (OW < 0) OW = W;
   float fx1 = (float)(a1 / (2.0 * W));
   float fx0 = (float)(a0 / (2.0 * W));
   float bias_x = bias * (a1 - a0) / (float)W;
   float delta = (float)EU_LANES * (a1 - a0) / (float)W;
-  for (int seg = 0; seg < W; seg += EU_SEGMENT)
-    for (int lane = 0; lane < EU_LANES && seg + lane < W; lane++) {
-      float ll0 = (float)(2 * lane) + (float)(seg * 2 + 1);
+  for (int seg = 0; seg < OW; seg += EU_SEGMENT)
+    for (int lane = 0; lane < EU_LANES && seg + lane < OW; lane++) {
+      float ll0 = (float)(2 * lane) + (float)((seg + x_off) * 2 + 1);
       float p = bias_x + ll0 * fx1 + ((float)(2 * W) - ll0) * fx0;
-      for (int x = seg + lane; x < W && x < seg + EU_SEGMENT; x += EU_LANES) {
+      for (int x = seg + lane; x < OW && x < seg + EU_SEGMENT; x += EU_LANES) {
         out[x] = p;
         p += delta;
       }
@@ -357,6 +362,20 @@ inline float planar_row(int H, float b0, float b1, float bias, int y)
   return bias_y + ll1 * fy1 + (float)(2 * H - ll1) * fy0;
 }
 
+// to_screen_t's LUT (envutil_payload.cc:251-287, :330-334): 256 knots of
+// 255 * RGB2sRGB(i / 255.0) evaluated in double with libm's pow, narrowed to
+// float, plus the NATURAL brace coefficient on the right (never weighted)
+inline void screen_lut(float *lut257)
+{
+  for (int i = 0; i < 256; i++) {
+    double x = i / double(256 - 1);
+    double r = 1.055 * std::pow(x, 0.41666666666666667) - 0.055;
+    if (x <= 0.0031308) r = 12.92 * x;
+    lut257[i] = (float)(r * 255.0);
+  }
+  lut257[256] = lut257[255] + lut257[255] - lut257[254];
+}
+
 // Fills the tables for one target. `normalize` is the stepper template flag:
 // false for single-facet rendering without twining, true otherwise
 // (envutil_payload.cc:2118, :2227). Returns false for an unknown projection.
@@ -364,14 +383,18 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
                                  bool twine, stepper_tables &tb)
 {
   const int W = t.width, H = t.height, prj = t.projection;
+  // store_cropped: OW x OH processed pixels starting at (X0, Y0) of the W x H frame
+  const bool crop = t.crop_w > 0;
+  const int OW = crop ? t.crop_w : W, OH = crop ? t.crop_h : H;
+  const int X0 = crop ? t.crop_x0 : 0, Y0 = crop ? t.crop_y0 : 0;
   const float a0 = (float)t.x0, a1 = (float)t.x1, b0 = (float)t.y0, b1 = (float)t.y1;
   float xx[3], yy[3], zz[3];
   for (int i = 0; i < 3; i++) { xx[i] = (float)basis.m[i]; yy[i] = (float)basis.m[3 + i]; zz[i] = (float)basis.m[6 + i]; }
-  tb.col.assign((size_t)4 * W, 0.0f);
-  tb.row.assign((size_t)H * EU_ROW_FLOATS, 0.0f);
-  std::vector<float> p0((size_t)W), p0b((size_t)W);
-  planar_columns(W, a0, a1, 0.0f, p0.data());
-  if (twine) planar_columns(W, a0, a1, 0.25f, p0b.data());
+  tb.col.assign((size_t)4 * OW, 0.0f);
+  tb.row.assign((size_t)OH * EU_ROW_FLOATS, 0.0f);
+  std::vector<float> p0((size_t)OW), p0b((size_t)OW);
+  planar_columns(W, a0, a1, 0.0f, p0.data(), X0, OW);
+  if (twine) planar_columns(W, a0, a1, 0.25f, p0b.data(), X0, OW);
   const float section_md = a1 - a0, refc_md = (float)((a1 - a0) / 2.0);
   const float q = (float)(M_PI / 4.0);
   tb.norm_mode = EU_NORM_NONE;
@@ -380,12 +403,12 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
     case EU_CYLINDRICAL:
       tb.form = EU_FORM_BCA;
       if (prj == EU_CYLINDRICAL && normalize) tb.norm_mode = EU_NORM_CYL;
-      for (int x = 0; x < W; x++) {
+      for (int x = 0; x < OW; x++) {
         tb.col[x] = std::sin(p0[x]);
-        tb.col[(size_t)W + x] = std::cos(p0[x]);
+        tb.col[(size_t)OW + x] = std::cos(p0[x]);
         if (twine) {
-          tb.col[(size_t)2 * W + x] = std::sin(p0b[x]);
-          tb.col[(size_t)3 * W + x] = std::cos(p0b[x]);
+          tb.col[(size_t)2 * OW + x] = std::sin(p0b[x]);
+          tb.col[(size_t)3 * OW + x] = std::cos(p0b[x]);
         }
       }
       break;
@@ -393,17 +416,17 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
     case EU_CUBEMAP:
       tb.form = EU_FORM_BA;
       if (normalize) tb.norm_mode = EU_NORM_DIV;
-      for (int x = 0; x < W; x++) {
+      for (int x = 0; x < OW; x++) {
         tb.col[x] = p0[x];
-        if (twine) tb.col[(size_t)2 * W + x] = p0b[x];
+        if (twine) tb.col[(size_t)2 * OW + x] = p0b[x];
       }
       break;
     case EU_BIATAN6:
       tb.form = EU_FORM_BA;
       if (normalize) tb.norm_mode = EU_NORM_DIV;
-      for (int x = 0; x < W; x++) {
+      for (int x = 0; x < OW; x++) {
         tb.col[x] = std::tan(p0[x] * q);
-        if (twine) tb.col[(size_t)2 * W + x] = std::tan(p0b[x] * q);
+        if (twine) tb.col[(size_t)2 * OW + x] = std::tan(p0b[x] * q);
       }
       break;
     case EU_FISHEYE:
@@ -412,17 +435,17 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
       // (:1146-1157) have no per-row or per-column invariant beyond the planar
       // coordinates themselves
       tb.form = prj == EU_FISHEYE ? EU_FORM_FISH : EU_FORM_STER;
-      for (int x = 0; x < W; x++) {
+      for (int x = 0; x < OW; x++) {
         tb.col[x] = p0[x];
-        if (twine) tb.col[(size_t)2 * W + x] = p0b[x];
+        if (twine) tb.col[(size_t)2 * OW + x] = p0b[x];
       }
       break;
     default:
       return false;
   }
-  for (int y = 0; y < H; y++) {
+  for (int y = 0; y < OH; y++) {
     for (int v = 0; v < (twine ? 2 : 1); v++) {
-      float p1 = planar_row(H, b0, b1, v ? 0.25f : 0.0f, y);
+      float p1 = planar_row(H, b0, b1, v ? 0.25f : 0.0f, y + Y0);
       float *r = &tb.row[(size_t)y * EU_ROW_FLOATS + EU_ROW_VARIANT * v];   // A, B, C, planar y
       r[9] = p1;
       switch (prj) {
@@ -442,7 +465,7 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
           for (int i = 0; i < 3; i++) { r[i] = xx[i]; r[3 + i] = yy[i]; r[6 + i] = zz[i]; }
           break;
         default: {               // cubemap, biatan6: stepper.h:1274-1358, :1449-1560
-          int face = y / W;
+          int face = (y + Y0) / W;
           float pp = p1 + (float)(3 - face) * section_md - refc_md;
           if (prj == EU_BIATAN6) pp = std::tan(pp * q);
           for (int i = 0; i < 3; i++) {

@@ -79,7 +79,14 @@ struct arguments : public facet_base
   int nchannels = 3;
   int nfacets = 0;
   std::vector<facet_spec> facet_spec_v;
-  float *p_output = nullptr;      // width x height x nchannels floats
+  float *p_output = nullptr;      // width x height x nchannels floats (crop size if store_cropped)
+  // PTO p-line crop (envutil_basic.h:684-687; envutil_payload.cc:440-474)
+  bool store_cropped = false;
+  int p_crop_x0 = 0, p_crop_x1 = 0, p_crop_y0 = 0, p_crop_y1 = 0;
+  // tethered rendering (envutil_basic.h; envutil_payload.cc:524-530): packed
+  // sRGBA8 words into caller-owned memory instead of float pixels
+  bool tethered = false;
+  void *p_screen_data = nullptr;
   bool verbose = false;
 
   // target extent and step, envutil_main.cc:1203-1232
@@ -136,7 +143,7 @@ struct hip_dispatch : public dispatch_base
   {
     if (projection != args.projection) return EU_ERR_ARGUMENT;
     if ((ninputs == 9) != !args.twine_spread.empty()) return EU_ERR_ARGUMENT;
-    if (!args.p_output) return EU_ERR_ARGUMENT;
+    if (args.tethered ? !args.p_screen_data : !args.p_output) return EU_ERR_ARGUMENT;
     std::vector<eu_source *> srcs;
     for (const auto &fct : args.facet_spec_v) {
       auto it = resident.find(fct.asset_key);
@@ -157,9 +164,19 @@ struct hip_dispatch : public dispatch_base
     t.nchannels = nchannels;
     t.ntaps = ninputs == 9 ? int(args.twine_spread.size()) : 0;
     t.taps = ninputs == 9 ? args.twine_spread[0].data() : nullptr;
-    t.row_begin = 0; t.row_end = args.height; t.stage = 0;
+    int w = args.width, h = args.height;
+    if (args.store_cropped) {
+      w = args.p_crop_x1 - args.p_crop_x0; h = args.p_crop_y1 - args.p_crop_y0;
+      t.crop_x0 = args.p_crop_x0; t.crop_y0 = args.p_crop_y0; t.crop_w = w; t.crop_h = h;
+    }
+    t.row_begin = 0; t.row_end = h; t.stage = 0;
+    if (args.tethered) {
+      t.out_format = EU_OUT_SRGBA8;
+      return eu_hip_render(&t, srcs.data(), int(srcs.size()), (float *)args.p_screen_data,
+                           size_t(w) * sizeof(uint32_t), 0, nullptr);
+    }
     return eu_hip_render(&t, srcs.data(), int(srcs.size()), args.p_output,
-                         size_t(args.width) * nchannels * sizeof(float), 0, nullptr);
+                         size_t(w) * nchannels * sizeof(float), 0, nullptr);
   }
 
   // conclude_cycle / asset_handler.cycle (environment.h:202-227): drop everything

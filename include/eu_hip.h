@@ -92,7 +92,20 @@ typedef struct eu_target {
   int32_t stage;                 /* 0 pixels; 1 rays; 2 source coordinates
                                     (stages 1/2 write 3 floats per pixel; used
                                     by the stage-wise parity tests)            */
+  /* args.store_cropped + p_crop_* (envutil_basic.h:684-687; applied at
+   * envutil_payload.cc:440-474): the job renders crop_w x crop_h pixels whose
+   * discrete coordinates start at (crop_x0, crop_y0) of the width x height
+   * frame (zimt's bill.get_offset). crop_w == 0: the whole frame. Rows,
+   * row_begin/row_end and the output buffer are those of the cropped frame.  */
+  int32_t crop_x0, crop_y0, crop_w, crop_h;
+  /* EU_OUT_FLOAT: nchannels floats per pixel (zimt::storer).
+   * EU_OUT_SRGBA8: one packed uint32 per pixel, the tethered 'act + to_screen_t'
+   * pipeline writing args.p_screen_data (envutil_payload.cc:251-413, :524-530);
+   * the output buffer is then uint32 and strides still count bytes.          */
+  int32_t out_format;
 } eu_target;
+
+enum { EU_OUT_FLOAT = 0, EU_OUT_SRGBA8 = 1 };
 
 /* ---- device / lifecycle ------------------------------------------------- */
 int  eu_hip_device_count(void);
@@ -151,7 +164,9 @@ int  eu_hip_source_release(eu_source *src);
  * out_on_device != 0: `out` is a device pointer, the call is asynchronous on
  * `stream` (a hipStream_t, NULL = the library's own stream) until
  * eu_hip_sync(); otherwise `out` is host memory and the call returns when the
- * rows are there. */
+ * rows are there. With trg->out_format == EU_OUT_SRGBA8 `out` points to uint32
+ * words (one per pixel, cast the pointer); with a crop window the rows are
+ * crop_w pixels wide. */
 int  eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc,
                    float *out, size_t out_row_stride_bytes, int out_on_device,
                    void *stream);

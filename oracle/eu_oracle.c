@@ -1022,6 +1022,7 @@ typedef struct {
   float fx0, fx1, fy0, fy1, bias_x, bias_y, delta;
   float xx[3], yy[3], zz[3];
   float section_md, refc_md;     /* cubemap/biatan6 */
+  int x_off, y_off;              /* bill.get_offset (wielding.h:215-224)   */
 } stepper_t;
 
 /* stepper.h:294-307 */
@@ -1049,6 +1050,7 @@ static void stepper_init(stepper_t *s, int projection, int normalize,
   }
   s->section_md = a1 - a0;
   s->refc_md = (float)((a1 - a0) / 2.0);
+  s->x_off = s->y_off = 0;
 }
 
 /* planar coordinate of pixel (x, y): stepper.h:324-350. The x value is the
@@ -1058,10 +1060,12 @@ static void planar_at(const stepper_t *s, int x, int y, float *p)
   int seg_start = (x / EUO_SEGMENT) * EUO_SEGMENT;
   int in_seg = x - seg_start;
   int lane = in_seg % EUO_LANES, k = in_seg / EUO_LANES;
-  float ll0 = (float)(2 * lane) + (float)(seg_start * 2 + 1);
+  /* segments start at multiples of 512 of the PROCESSED shape; the offset is
+   * added to the coordinate handed to init (wielding.h:215-224) */
+  float ll0 = (float)(2 * lane) + (float)((seg_start + s->x_off) * 2 + 1);
   float p0 = s->bias_x + ll0 * s->fx1 + ((float)(2 * s->width) - ll0) * s->fx0;
   for (int i = 0; i < k; i++) p0 += s->delta;
-  int ll1 = y * 2 + 1;
+  int ll1 = (y + s->y_off) * 2 + 1;
   float p1 = s->bias_y + ll1 * s->fy1 + (float)(2 * s->height - ll1) * s->fy0;
   p[0] = p0;
   p[1] = p1;
@@ -1151,7 +1155,7 @@ static void stepper_ray(const stepper_t *s, int x, int y, float *trg)
     }
     case EUO_CUBEMAP:
     case EUO_BIATAN6: {         /* stepper.h:1274-1358, :1449-1560 */
-      int face = y / s->width;
+      int face = (y + s->y_off) / s->width;
       float p1 = pl[1] + (float)(3 - face) * s->section_md - s->refc_md;
       float p0 = pl[0];
       if (s->projection == EUO_BIATAN6) {
@@ -1305,16 +1309,6 @@ static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
   if (dbg) { dbg[0] = s0; dbg[1] = s1; dbg[2] = 0.0f; }
   ev_eval(&m->ev, s0, s1, px);
   return 1;
-}
-
-/* environment::eval brighten, environment.h:1821-1842 */
-static void brighten_px(const mount_t *m, float *px)
-{
-  int nch = m->src->spl.nch;
-  if (m->brighten != 1.0f) {
-    int ncol = (nch == 2 || nch == 4) ? nch - 1 : nch;
-    for (int c = 0; c < ncol; c++) px[c] *= m->brighten;
-  }
 }
 
 /* repix_t, environment.h:1205-1309: channel-count adaption */
@@ -1528,10 +1522,74 @@ static void synopsis_group(const syn_t *sy, float rays[][EUO_LANES][3], int n, f
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* to_screen_t (envutil_payload.cc:225-413): lut_based_tf = degree-1          */
+/* bspline<float,1>(256, NATURAL) over 255 * RGB2sRGB(i / 255.0), evaluated   */
+/* through make_safe_evaluator (clamp gate [0, 255], eval.h:2096-2104) at     */
+/* in * 255.0f; the float results convert to uint32 by truncation and pack.   */
+/* ------------------------------------------------------------------------ */
+
+void euo_screen_lut(float *lut)
+{
+  for (int i = 0; i < 256; i++) {
+    double x = i / (double)(256 - 1);
+    double r = 1.055 * pow(x, 0.41666666666666667) - 0.055;
+    if (x <= 0.0031308) r = 12.92 * x;
+    double y = r * 255.0;
+    lut[i] = (float)y;
+  }
+  /* NATURAL brace, one coefficient to the right (brace.h:134+): point mirror */
+  lut[256] = lut[255] + lut[255] - lut[254];
+}
+
+float euo_lut_eval(const float *lut, float in)
+{
+  float c = in * (float)(256 - 1);
+  if (c < 0.0f) c = 0.0f;            /* clamp_gate, map.h:184-231 */
+  else if (c > 255.0f) c = 255.0f;
+  if (c != c) return 0.0f;           /* NaN: undefined in the reference */
+  float fl = floorf(c);
+  float t = c - fl;
+  int i = (int)fl;
+  float wl = 1.0f - t, wr = t;       /* _eval_linear<0>, eval.h:1040-1059 */
+  float sum = lut[i];
+  sum *= wl;
+  sum += lut[i + 1] * wr;
+  return sum;
+}
+
+static unsigned screen_channel(const float *lut, float in)
+{
+  return (unsigned)euo_lut_eval(lut, in);
+}
+
+unsigned euo_to_screen(const float *lut, int nch, const float *px)
+{
+  unsigned out;
+  if (nch == 1) {
+    unsigned ch = screen_channel(lut, px[0]);
+    out = 0xFF00; out |= ch; out <<= 8; out |= ch; out <<= 8; out |= ch;
+  } else if (nch == 2) {
+    unsigned c1 = screen_channel(lut, px[0]), c2 = screen_channel(lut, px[1]);
+    out = c2; out <<= 8; out |= c1; out <<= 8; out |= c1; out <<= 8; out |= c1;
+  } else if (nch == 3) {
+    unsigned c1 = screen_channel(lut, px[0]), c2 = screen_channel(lut, px[1]),
+             c3 = screen_channel(lut, px[2]);
+    out = 0xFF00; out |= c3; out <<= 8; out |= c2; out <<= 8; out |= c1;
+  } else {
+    unsigned c1 = screen_channel(lut, px[0]), c2 = screen_channel(lut, px[1]),
+             c3 = screen_channel(lut, px[2]), c4 = screen_channel(lut, px[3]);
+    out = c4; out <<= 8; out |= c3; out <<= 8; out |= c2; out <<= 8; out |= c1;
+  }
+  return out;
+}
+
 static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc,
                             float *out, long ors)
 {
-  int nch = job->nch, W = job->width;
+  int nch = job->nch, W = job->crop_w > 0 ? job->crop_w : job->width;
+  float lut[257];
+  euo_screen_lut(lut);
   if (nsrc > EUO_MAX_FACETS) return -2;
   syn_t *sy = (syn_t *)calloc(1, sizeof(syn_t));
   stepper_t *st = (stepper_t *)calloc(3 * (size_t)nsrc, sizeof(stepper_t));
@@ -1545,9 +1603,11 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
     euo_make_r3(srcs[f].roll, srcs[f].pitch, srcs[f].yaw, 1, r_fct);
     euo_rotate_r3(r_cam, r_fct, basis);
     /* multi-facet steppers are built with normalize = true (payload.cc:2152) */
-    stepper_init(&st[3 * f], job->projection, 1, basis, W, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.0f);
-    stepper_init(&st[3 * f + 1], job->projection, 1, basis, W, job->height, job->x0, job->x1, job->y0, job->y1, 0.25f, 0.0f);
-    stepper_init(&st[3 * f + 2], job->projection, 1, basis, W, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.25f);
+    stepper_init(&st[3 * f], job->projection, 1, basis, job->width, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.0f);
+    stepper_init(&st[3 * f + 1], job->projection, 1, basis, job->width, job->height, job->x0, job->x1, job->y0, job->y1, 0.25f, 0.0f);
+    stepper_init(&st[3 * f + 2], job->projection, 1, basis, job->width, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.25f);
+    if (job->crop_w > 0)
+      for (int v = 0; v < 3; v++) { st[3 * f + v].x_off = job->crop_x0; st[3 * f + v].y_off = job->crop_y0; }
     mount_init(&sy->mnt[f], &srcs[f]);
     sy->recip_step[f] = (float)(1.0 / srcs[f].step);
   }
@@ -1601,8 +1661,10 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
           }
           memcpy(px, acc, sizeof acc);
         }
-        for (int l = 0; l < n; l++)
+        for (int l = 0; l < n; l++) {
+          if (job->screen) { ((unsigned *)row)[x0 + l] = euo_to_screen(lut, nch, px[l]); continue; }
           for (int c = 0; c < nch; c++) row[(long)(x0 + l) * nch + c] = px[l][c];
+        }
       }
     free(rays); free(p0); free(du); free(dv);
   }
@@ -1631,6 +1693,12 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
                job->x0, job->x1, job->y0, job->y1, 0.25f, 0.0f);
   stepper_init(&st01, job->projection, 1, basis, job->width, job->height,
                job->x0, job->x1, job->y0, job->y1, 0.0f, 0.25f);
+  if (job->crop_w > 0) {
+    st00.x_off = st10.x_off = st01.x_off = job->crop_x0;
+    st00.y_off = st10.y_off = st01.y_off = job->crop_y0;
+  }
+  float lut[257];
+  euo_screen_lut(lut);
   mount_t mnt;
   mount_init(&mnt, src);
   /* twine_t ctor: x and y of every tap pre-multiplied by 4 (twining.h:106-121) */
@@ -1644,7 +1712,7 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
     }
   }
   int nthreads = job->nthreads > 0 ? job->nthreads : 1;
-  int W = job->width;
+  int W = job->crop_w > 0 ? job->crop_w : job->width;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
   for (int y = job->row_begin; y < job->row_end; y++) {
     float *row = out + (long)(y - job->row_begin) * ors;
@@ -1661,6 +1729,7 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
           row[3 * x] = dbg[0]; row[3 * x + 1] = dbg[1]; row[3 * x + 2] = dbg[2];
           continue;
         }
+        if (job->screen) { ((unsigned *)row)[x] = euo_to_screen(lut, nch, px); continue; }
         for (int c = 0; c < nch; c++) row[(long)x * nch + c] = px[c];
       } else {
         float r10[3], r01[3], dx[3], dy[3], acc[4] = { 0, 0, 0, 0 };
@@ -1674,6 +1743,7 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
           env_eval(&mnt, in_k, nch, px, NULL);
           for (int c = 0; c < nch; c++) acc[c] += taps[3 * k + 2] * px[c];
         }
+        if (job->screen) { ((unsigned *)row)[x] = euo_to_screen(lut, nch, acc); continue; }
         for (int c = 0; c < nch; c++) row[(long)x * nch + c] = acc[c];
       }
     }

@@ -81,7 +81,20 @@ typedef struct {
   int row_begin, row_end;      /* rows [row_begin,row_end) are rendered    */
   int stage;                   /* 0 pixels, 1 rays, 2 source coordinate    */
   int nthreads;
+  /* store_cropped (envutil_payload.cc:440-474): the output is crop_w x crop_h
+   * and the discrete coordinates fed to the stepper are raised by
+   * (crop_x0, crop_y0); crop_w == 0: no cropping. rows and row_begin/row_end
+   * count in the cropped frame. */
+  int crop_x0, crop_y0, crop_w, crop_h;
+  /* 1: 'act + to_screen_t' (envutil_payload.cc:251-413, :524-530): one packed
+   * sRGBA8 uint32 per pixel; out is then a uint32 buffer, stride in words */
+  int screen;
 } euo_job;
+
+/* to_screen_t's LUT (256 knots of 255 * sRGB(i / 255), float) and one pixel */
+void   euo_screen_lut(float *lut257);
+float  euo_lut_eval(const float *lut257, float in);   /* lut_based_tf::eval, one lane */
+unsigned euo_to_screen(const float *lut257, int nch, const float *px);
 
 /* set-up arithmetic */
 double euo_get_vfov(int projection, int width, int height, double hfov);

@@ -243,4 +243,22 @@ void ref_filter_2d(float *data, long w, long h, int nch, int degree, int bc0,
 #undef REF_F2D
 }
 
+// The zimt calls lut_based_tf makes (envutil_payload.cc:251-287): a 1-D
+// degree-1 bspline<float,1> with NATURAL boundary over `size` knots,
+// prefilter(), make_safe_evaluator, evaluated at in * float(size - 1) on
+// 16-lane vectors. `knots` come from the caller (the sRGB curve needs no zimt).
+void ref_lut_eval(const float *knots, long size, const float *in, long n, float *out) {
+  zimt::bspline<float, 1> lut(size, 1, zimt::NATURAL);
+  for (long i = 0; i < size; i++) lut.core[i] = knots[i];
+  lut.prefilter();
+  auto gev = zimt::make_safe_evaluator<zimt::bspline<float, 1>, float, L>(lut);
+  typedef zimt::simdized_type<float, L> f_v;
+  for (long i = 0; i < n; i += L) {
+    f_v v(0.0f), r;
+    for (std::size_t l = 0; l < L && i + long(l) < n; l++) v[l] = in[i + l];
+    gev.eval(v * float(size - 1), r);
+    for (std::size_t l = 0; l < L && i + long(l) < n; l++) out[i + l] = r[l];
+  }
+}
+
 }  // extern "C"

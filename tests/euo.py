@@ -46,7 +46,9 @@ class Job(C.Structure):
                 ("nch", C.c_int), ("ntaps", C.c_int),
                 ("taps", C.POINTER(C.c_float)),
                 ("row_begin", C.c_int), ("row_end", C.c_int),
-                ("stage", C.c_int), ("nthreads", C.c_int)]
+                ("stage", C.c_int), ("nthreads", C.c_int),
+                ("crop_x0", C.c_int), ("crop_y0", C.c_int), ("crop_w", C.c_int), ("crop_h", C.c_int),
+                ("screen", C.c_int)]
 
 
 class Metrics(C.Structure):

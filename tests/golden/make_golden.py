@@ -91,6 +91,21 @@ def main():
     out["drv_aff"] = aff
     out["drv_out"] = r.process_affine(600, 3, aff)
     out["drv_short"] = r.process_affine(11, 2, aff)
+    # to_screen_t's LUT evaluation (envutil_payload.cc:251-287): 1-D degree-1
+    # NATURAL spline over 255 * sRGB(i / 255), clamp gate, at in * 255.0f
+    x = np.arange(256) / 255.0
+    y = np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 0.41666666666666667) - 0.055) * 255.0
+    knots = y.astype(np.float32)
+    one = np.float32(1.0)
+    vin = np.concatenate([
+        np.linspace(-0.05, 1.05, 6000).astype(np.float32),
+        (np.arange(256) / 255.0).astype(np.float32),
+        rng.random(6000, dtype=np.float32),
+        np.array([0.0, -0.0, 1.0, 1e-8, 0.0031308, np.nextafter(one, np.float32(0)),
+                  np.nextafter(one, np.float32(2)), 0.5, 254.5 / 255.0, 2.0, -3.0, 1e30], np.float32)])
+    out["lut_knots"] = knots
+    out["lut_in"] = vin
+    out["lut_out"] = refz.lut_eval(knots, vin)
     np.savez_compressed(os.path.join(HERE, "zimt_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "zimt_golden.npz"),
           os.path.getsize(os.path.join(HERE, "zimt_golden.npz")), "bytes")

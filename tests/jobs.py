@@ -118,9 +118,22 @@ def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8, nc
     j.row_end = args.height if row_end is None else row_end
     j.stage = stage
     j.nthreads = nthreads
+    w = args.width
+    if getattr(args, "store_cropped", False):
+        x0, x1, y0, y1 = args.p_crop
+        j.crop_x0, j.crop_y0, j.crop_w, j.crop_h = x0, y0, x1 - x0, y1 - y0
+        w = x1 - x0
+        if row_end is None:
+            j.row_end = y1 - y0
+    if getattr(args, "tethered", False):
+        j.screen = 1
+        out = np.zeros((j.row_end - j.row_begin, w), np.uint32)
+        rc = euo.lib().euo_render(C.byref(j), arr, len(srcs), out.ctypes.data_as(C.c_void_p), w)
+        assert rc == 0, rc
+        return out
     och = 3 if stage else (nch or osrc.nch)
-    out = np.zeros((j.row_end - j.row_begin, args.width, och), np.float32)
-    rc = euo.lib().euo_render(C.byref(j), arr, len(srcs), euo.ptr(out), args.width * och)
+    out = np.zeros((j.row_end - j.row_begin, w, och), np.float32)
+    rc = euo.lib().euo_render(C.byref(j), arr, len(srcs), euo.ptr(out), w * och)
     assert rc == 0, rc
     return out
 

@@ -109,3 +109,15 @@ def filter_2d(img, degree, bc0, bc1):
     h, w, nch = a.shape
     lib().ref_filter_2d(ptr(a), w, h, nch, degree, bc0, bc1)
     return a
+
+
+def lut_eval(knots, vin):
+    """lut_based_tf's zimt calls (envutil_payload.cc:251-287) on `knots`"""
+    knots = np.ascontiguousarray(knots, np.float32)
+    vin = np.ascontiguousarray(vin, np.float32)
+    out = np.zeros_like(vin)
+    f = lib().ref_lut_eval
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
+    f(knots.ctypes.data, len(knots), vin.ctypes.data, len(vin), out.ctypes.data)
+    return out

@@ -299,3 +299,77 @@ def test_pixels_polar_targets(latlon, tprj, tw, th, thfov, twine):
     o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 3)
     a = ea.arguments(tprj, tw, th, thfov, yaw=70, pitch=-25, roll=11, spline_degree=3, twine=twine)
     assert_bits(ea.render(a, g), jobs.oracle_render(a, o), f"pixels prj {tprj} twine {twine}")
+
+
+# ---- store_cropped and the tethered put stage -----------------------------------
+
+CROPS = [(512, 700, 10, 50),       # starts on a segment boundary
+         (37, 649, 3, 41),         # ragged: segments of the crop differ from the frame's
+         (600, 616, 0, 64),        # one vector wide
+         (0, 700, 0, 64)]          # the whole frame, as a crop
+
+
+@pytest.mark.parametrize("crop", CROPS)
+@pytest.mark.parametrize("tprj,th,thfov", [(ea.SPHERICAL, 64, 360.0), (ea.CYLINDRICAL, 64, 300.0),
+                                           (ea.RECTILINEAR, 64, 100.0)])
+def test_cropped_output_bit_exact(latlon, crop, tprj, th, thfov):
+    """args.store_cropped (envutil_payload.cc:440-474): crop-sized output, the
+    stepper sees coordinates raised by the crop origin"""
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 3)
+    for twine in (0, 2):
+        a = ea.arguments(tprj, 700, th, thfov, yaw=31, pitch=-12, roll=6, spline_degree=3,
+                         twine=twine, crop=crop)
+        got, ref = ea.render(a, g), jobs.oracle_render(a, o)
+        assert got.shape == (crop[3] - crop[2], crop[1] - crop[0], 3)
+        assert_bits(got, ref, f"crop {crop} prj {tprj} twine {twine}")
+
+
+def test_cropped_cubemap_target_and_rows(latlon):
+    """crop of a cubemap target straddling two faces (face = (y + y0) / width),
+    rendered in two row tiles"""
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 1)
+    a = ea.arguments(ea.CUBEMAP, 48, 288, 90.0, yaw=5, spline_degree=1, crop=(5, 40, 30, 120))
+    ref = jobs.oracle_render(a, o)
+    got = np.concatenate([ea.render(a, g, row_begin=0, row_end=33), ea.render(a, g, row_begin=33)])
+    assert_bits(got, ref, "cropped cubemap target")
+    with pytest.raises(ea.EuError):
+        ea.render(ea.arguments(ea.SPHERICAL, 64, 32, 360.0, crop=(0, 65, 0, 32)), g)
+
+
+def test_cropped_multi_facet():
+    os_, gs = facet_set(euo.RECTILINEAR, 72, 72, 95.0, 4, 1, seed=3)
+    a = ea.arguments(ea.SPHERICAL, 640, 320, 360.0, yaw=20, spline_degree=1, crop=(101, 640, 17, 200))
+    assert_bits(ea.render(a, gs, 4), jobs.oracle_render(a, os_), "cropped multi-facet")
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3, 4])
+@pytest.mark.parametrize("twine", [0, 2])
+def test_tethered_srgba8_words(nch, twine):
+    """act + to_screen_t (envutil_payload.cc:251-413, :524-530): identical
+    packed words, general and packed kernels, with values outside [0, 1]"""
+    img = jobs.synth_image(SRC_W, SRC_H, nch) * 1.6 - 0.2
+    if nch in (2, 4):
+        img[:, :, nch - 1] = jobs.synth_image(SRC_W, SRC_H, 1, seed=99)[:, :, 0]
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, img, 3)
+    for tprj, tw, th, thfov in [(ea.RECTILINEAR, 333, 77, 90.0), (ea.SPHERICAL, 300, 150, 360.0)]:
+        a = ea.arguments(tprj, tw, th, thfov, yaw=12, pitch=7, spline_degree=3, twine=twine, tethered=True)
+        got, ref = ea.render(a, g), jobs.oracle_render(a, o)
+        assert got.dtype == np.uint32 and got.shape == (th, tw)
+        assert np.array_equal(got, ref), f"{(got != ref).sum()} words differ"
+        assert len(np.unique(got)) > 100
+    # general kernel (a rectilinear source is not on the packed path), cropped
+    o, g = make_pair(euo.RECTILINEAR, 200, 150, 80.0, jobs.synth_image(200, 150, nch), 1)
+    a = ea.arguments(ea.SPHERICAL, 300, 150, 360.0, spline_degree=1, twine=twine, tethered=True,
+                     crop=(100, 220, 40, 110))
+    assert np.array_equal(ea.render(a, g), jobs.oracle_render(a, o))
+
+
+def test_tethered_multi_facet_and_repix():
+    os_, gs = facet_set(euo.RECTILINEAR, 72, 72, 95.0, 4, 1, seed=3)
+    a = ea.arguments(ea.SPHERICAL, 200, 100, 360.0, yaw=20, spline_degree=1, tethered=True)
+    assert np.array_equal(ea.render(a, gs, 4), jobs.oracle_render(a, os_))
+    # 3-channel source shown through a 4-channel job: repix, then to_screen
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, jobs.synth_image(SRC_W, SRC_H, 3), 1)
+    a = ea.arguments(ea.RECTILINEAR, 120, 90, 80.0, spline_degree=1, tethered=True)
+    got, ref = ea.render(a, g, 4), jobs.oracle_render(a, o, nch=4)
+    assert np.array_equal(got, ref) and (got >> 24 == 255).all()

@@ -83,3 +83,37 @@ def test_driver_raster(name, w, h):
     y = np.arange(h, dtype=np.float32) * a[3] + a[2]
     crd = np.stack(np.broadcast_arrays(x[None, :], y[:, None]), -1).reshape(-1, 2)
     assert_same(s.eval(crd).reshape(h, w, 3), G[name])
+
+
+def test_screen_lut_knots_and_eval():
+    """to_screen_t: the oracle's sRGB LUT and its clamp + linear evaluation
+    against zimt's bspline<float,1> / make_safe_evaluator (fixture)"""
+    import ctypes as C
+    L = euo.lib()
+    lut = np.zeros(257, np.float32)
+    L.euo_screen_lut(lut.ctypes.data_as(C.c_void_p))
+    assert_same(lut[:256], G["lut_knots"])
+    L.euo_lut_eval.restype = C.c_float
+    L.euo_lut_eval.argtypes = [C.c_void_p, C.c_float]
+    got = np.array([L.euo_lut_eval(lut.ctypes.data, float(v)) for v in G["lut_in"]], np.float32)
+    assert_same(got, G["lut_out"])
+
+
+def test_to_screen_packing():
+    """channel order of the packed sRGBA8 word (envutil_payload.cc:357-410)"""
+    import ctypes as C
+    L = euo.lib()
+    lut = np.zeros(257, np.float32)
+    L.euo_screen_lut(lut.ctypes.data_as(C.c_void_p))
+    L.euo_to_screen.restype = C.c_uint
+    L.euo_to_screen.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    px = np.array([1.0, 0.0, 0.2140411, 0.5], np.float32)
+    def ts(n):
+        return L.euo_to_screen(lut.ctypes.data, n, px.ctypes.data)
+    assert ts(1) == 0xFFFFFFFF
+    assert ts(2) == 0x00FFFFFF
+    w3 = ts(3)
+    assert (w3 >> 24) == 0xFF and (w3 & 0xFF) == 255 and ((w3 >> 8) & 0xFF) == 0
+    assert ((w3 >> 16) & 0xFF) in (126, 127, 128)      # sRGB(0.214) ~ 0.5
+    w4 = ts(4)
+    assert (w4 >> 24) in (186, 187, 188) and (w4 & 0xFFFFFF) == (w3 & 0xFFFFFF)

@@ -92,3 +92,37 @@ def test_cubemap_of_latlon_round_trip():
     oc = jobs.OracleSource(euo.CUBEMAP, 128, 768, 90.0, cube, 3)
     back = jobs.oracle_render(ea.arguments(ea.SPHERICAL, 512, 256, 360.0, spline_degree=3), oc)
     assert np.abs(back - img).max() < 5e-3
+
+
+def test_cropped_render_is_a_window_of_the_frame():
+    """store_cropped (envutil_payload.cc:440-474): a crop that starts on a
+    512-pixel segment boundary reproduces the frame's pixels bit for bit (same
+    segment starts, same number of delta additions); any other crop origin
+    restarts the segments and agrees to rounding only"""
+    img = jobs.synth_image(128, 64, 3)
+    o = jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img, 3)
+    kw = dict(yaw=25, pitch=10, roll=-4, spline_degree=3)
+    full = jobs.oracle_render(ea.arguments(ea.RECTILINEAR, 1100, 40, 100.0, **kw), o)
+    a = ea.arguments(ea.RECTILINEAR, 1100, 40, 100.0, crop=(512, 1100, 7, 33), **kw)
+    part = jobs.oracle_render(a, o)
+    assert part.shape == (26, 588, 3)
+    assert (jobs.bits(part) == jobs.bits(full[7:33, 512:1100])).all()
+    a = ea.arguments(ea.RECTILINEAR, 1100, 40, 100.0, crop=(37, 700, 0, 40), **kw)
+    part = jobs.oracle_render(a, o)
+    assert np.abs(part - full[:, 37:700]).max() < 1e-4
+    assert (jobs.bits(part) != jobs.bits(full[:, 37:700])).any()
+
+
+def test_tethered_words_follow_the_float_pixels():
+    """to_screen_t: each byte is the truncated LUT value of the float pixel -
+    within 1 of 255 * sRGB(v), alpha 255 for RGB"""
+    img = jobs.synth_image(128, 64, 3)
+    o = jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img, 1)
+    fl = jobs.oracle_render(ea.arguments(ea.SPHERICAL, 90, 45, 360.0, spline_degree=1), o)
+    w = jobs.oracle_render(ea.arguments(ea.SPHERICAL, 90, 45, 360.0, spline_degree=1, tethered=True), o)
+    assert w.dtype == np.uint32 and (w >> 24 == 255).all()
+    v = np.clip(fl.astype(np.float64), 0.0, 1.0)
+    srgb = np.where(v <= 0.0031308, 12.92 * v, 1.055 * v ** (1 / 2.4) - 0.055) * 255.0
+    for c in range(3):
+        byte = ((w >> (8 * c)) & 0xFF).astype(np.float64)
+        assert np.all(byte <= srgb[:, :, c] + 0.51) and np.all(byte >= srgb[:, :, c] - 1.01)
