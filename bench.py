@@ -124,6 +124,7 @@ def main():
     else:
         fcts = [ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch)]
     t_setup = time.time()
+    t_load = 0.0
     sources = []
     for fct in fcts:
         if rank == 0:
@@ -133,7 +134,9 @@ def main():
             host = img.cpu().numpy()
             del img
             torch.cuda.empty_cache()
+            tl = time.perf_counter()
             s1 = ea.Source.load(fct, host, degree)       # H2D + device prefilter/brace
+            t_load += time.perf_counter() - tl
             del host
         else:
             s1 = ea.Source.alloc(fct, degree)
@@ -197,10 +200,19 @@ def main():
         del frame
 
     # ---- kernel-only time with HIP events on the kernel's stream ------------
-    if nsrcs == 1:
-        kernel_ms = ea.render_timed(args, src, out.data_ptr(), max(a.steps, 5), nch, r0, r1)
-    else:
-        kernel_ms = 1e3 * elapsed / a.steps     # multi-facet: no separate event path yet; step time
+    kernel_ms = ea.render_timed(args, sources, out.data_ptr(), max(a.steps, 5), nch, r0, r1)
+
+    # ---- the boundary with HOST buffers (never `value`): pixels in, pixels out ----
+    # load = H2D of the source + prefilter/brace on the device; render_to_host =
+    # kernel + D2H of the frame into pageable memory (second call: pages touched)
+    host_ms = None
+    if world == 1 and nsrcs == 1 and not a.no_cpu_baseline:
+        hbuf = np.empty((r1 - r0, tw, nch), np.float32)
+        ea.render(args, src, nch, r0, r1, out=hbuf)
+        th0 = time.perf_counter()
+        ea.render(args, src, nch, r0, r1, out=hbuf)
+        host_ms = 1e3 * (time.perf_counter() - th0)
+        del hbuf
 
     probe = None
     if a.probe_stages:
@@ -257,7 +269,10 @@ def main():
                    "channels": nch, "spline_degree": degree, "twine": twine,
                    "rows_per_gpu": r1 - r0, "tiling": f"rows/{world}",
                    "gather_ms_untimed": None if gather_ms is None else round(gather_ms, 3),
-                   "setup_s": round(t_setup, 2)},
+                   "setup_s": round(t_setup, 2),
+                   "host_boundary": {"source_load_s": round(t_load, 3),
+                                     "render_to_host_ms": None if host_ms is None else round(host_ms, 1),
+                                     "note": "pageable host memory over PCIe; not part of value"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic,

@@ -655,13 +655,19 @@ int eu_hip_render_timed(const eu_target *trg, eu_source *const *srcs, int nsrc, 
   if ((rc = ensure_init())) return rc;
   if (iters <= 0 || !mean_ms) return fail(EU_ERR_ARGUMENT, "bad iteration count");
   eu_render_params p;
-  if ((rc = build_params(trg, srcs, nsrc, out_dev, out_row_stride_bytes, &p))) return rc;
+  multi_params mp;
+  int mdeg = 0;
+  if (!srcs || nsrc < 1 || !trg) return fail(EU_ERR_ARGUMENT, "no source");
+  const bool multi = nsrc > 1;
+  if (multi) { if ((rc = build_multi(trg, srcs, nsrc, out_dev, out_row_stride_bytes, &mp, &mdeg))) return rc; }
+  else if ((rc = build_params(trg, srcs, nsrc, out_dev, out_row_stride_bytes, &p))) return rc;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, g.stream));
   for (int i = 0; i < iters; i++)
-    if (launch_render(&p, g.stream)) return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
+    if (multi ? eu_launch_render_multi(&mp, mdeg, g.stream) : launch_render(&p, g.stream))
+      return fail(EU_ERR_NO_DEVICE, "kernel launch failed");
   HIPCHK(hipEventRecord(e1, g.stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.0f;

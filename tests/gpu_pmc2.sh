@@ -3,7 +3,7 @@
 set -e
 R="$GRAFT_REPO_ROOT"; cd "$R"; rm -rf gpurun_out/pmc2; mkdir -p gpurun_out/pmc2
 export TMPDIR=/tmp
-GROUPS_="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU|FETCH_SIZE|TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum|GRBM_GUI_ACTIVE SPI_CSN_BUSY SPI_CSN_WAVE"
+GROUPS_="${PMC_GROUPS:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU|FETCH_SIZE|TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum|GRBM_GUI_ACTIVE SPI_CSN_BUSY SPI_CSN_WAVE}"
 IFS='|' read -ra GS <<< "$GROUPS_"
 for kv in ${VARIANTS}; do
   i=0
