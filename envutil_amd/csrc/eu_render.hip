@@ -86,10 +86,6 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
         for (int c = 0; c < on; c++) acc[c] = acc[c] + cw * q4[c];
       }
     }
-    if (p.lut) {
-      reinterpret_cast<unsigned *>(dst)[x] = eu_to_screen(p.lut, on, acc);
-      return;
-    }
     float *o4 = dst + (long long)x * on;
     for (int c = 0; c < on; c++) o4[c] = acc[c];
     return;
@@ -118,7 +114,7 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
       for (int c = 0; c < NCH; c++) px[c] = px[c] + cw * q[c];
     }
   }
-  eu_put<NCH>(dst, p.lut, x, px);
+  eu_put<NCH>(dst, x, px);
 }
 
 // ---------------------------------------------------------------------------
@@ -235,7 +231,7 @@ __global__ __launch_bounds__(256) void eu_render_lds_kernel(const eu_render_para
 #pragma unroll
     for (int c = 0; c < ncol; c++) px[c] = px[c] * p.src.brighten;
   }
-  eu_put<NCH>(p.out + (long long)(y - p.row_begin) * p.out_stride, p.lut, x, px);
+  eu_put<NCH>(p.out + (long long)(y - p.row_begin) * p.out_stride, x, px);
 }
 
 // ---------------------------------------------------------------------------

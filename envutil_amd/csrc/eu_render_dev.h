@@ -443,53 +443,17 @@ __device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, fl
 }
 
 // ---------------------------------------------------------------------------
-// put side. Float pixels (zimt::storer + fluff, put.h:122-136) or the tethered
-// pipeline's to_screen_t (envutil_payload.cc:251-413): every channel goes
-// through lut_based_tf - in * 255.0f, clamp gate [0, 255] (NATURAL spline,
-// eval.h:2096-2104), linear interpolation between two knots of the sRGB LUT
-// (wl = 1 - t; s = c0 * wl; s += c1 * t), truncation to uint32 - and the
-// words are packed A<<24 | B<<16 | G<<8 | R.
+// put side: zimt::storer + fluff (put.h:122-136), one pixel into its output row.
+// The tethered pipeline's to_screen_t runs as a separate pass over the float
+// frame (eu_setup.hip: to_screen_kernel) so that no render kernel carries it.
 // ---------------------------------------------------------------------------
 
-__device__ __forceinline__ unsigned eu_screen_channel(const float *__restrict__ lut, float v)
-{
-  float c = v * 255.0f;
-  c = c < 0.0f ? 0.0f : c;
-  c = c > 255.0f ? 255.0f : c;
-  const float fl = floorf(c);
-  const float t = c - fl;
-  int i = (int)fl;
-  i = min(max(i, 0), 255);            // NaN input (undefined in the reference): stay in the table
-  const float wl = 1.0f - t;
-  float s = lut[i] * wl;
-  s = s + lut[i + 1] * t;
-  return (unsigned)s;
-}
-
-__device__ __forceinline__ unsigned eu_to_screen(const float *__restrict__ lut, int nch, const float *px)
-{
-  const unsigned c1 = eu_screen_channel(lut, px[0]);
-  if (nch == 1) return 0xFF000000u | (c1 << 16) | (c1 << 8) | c1;
-  const unsigned c2 = eu_screen_channel(lut, px[1]);
-  if (nch == 2) return (c2 << 24) | (c1 << 16) | (c1 << 8) | c1;
-  const unsigned c3 = eu_screen_channel(lut, px[2]);
-  if (nch == 3) return 0xFF000000u | (c3 << 16) | (c2 << 8) | c1;
-  const unsigned c4 = eu_screen_channel(lut, px[3]);
-  return (c4 << 24) | (c3 << 16) | (c2 << 8) | c1;
-}
-
-// one pixel into its output row (row: start of the row in the output buffer)
 template <int NCH>
-__device__ __forceinline__ void eu_put(float *row, const float *__restrict__ lut, int x,
-                                       const float *px)
+__device__ __forceinline__ void eu_put(float *row, int x, const float *px)
 {
-  if (lut) {
-    reinterpret_cast<unsigned *>(row)[x] = eu_to_screen(lut, NCH, px);
-  } else {
-    float *o = row + (long long)x * NCH;
+  float *o = row + (long long)x * NCH;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) o[c] = px[c];
-  }
+  for (int c = 0; c < NCH; c++) o[c] = px[c];
 }
 
 // ---------------------------------------------------------------------------

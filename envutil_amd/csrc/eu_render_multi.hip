@@ -30,7 +30,6 @@ struct eu_multi_params {
   float *out;
   long long out_stride;
   int tiles_x, tiles_y;
-  const float *lut;          // to_screen_t LUT or null (eu_put)
 };
 
 struct eu_pix { int x, y; };
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(256) void eu_render_multi_kernel(const eu_multi_par
     }
   }
   if (!live) return;
-  eu_put<NCH>(p.out + (long long)(px.y - p.row_begin) * p.out_stride, p.lut, px.x, out);
+  eu_put<NCH>(p.out + (long long)(px.y - p.row_begin) * p.out_stride, px.x, out);
 }
 
 template <int NCH, bool PLUS>

@@ -498,3 +498,85 @@ extern "C" int eu_verify_const_div(float c, float limit, void *stream)
   (void)hipFree(bad);
   return h ? 0 : 1;
 }
+
+
+// ---------------------------------------------------------------------------
+// channel-planar copy of an interleaved container (derived data for the packed
+// cubic kernel): dst[c][i] = src[i * nch + c]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deinterleave_kernel(const float *__restrict__ src,
+                                                           float *__restrict__ dst,
+                                                           long long ntexels, int nch)
+{
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntexels) return;
+  for (int c = 0; c < nch; c++) dst[(long long)c * ntexels + i] = src[i * nch + c];
+}
+
+extern "C" int eu_launch_deinterleave(const float *src, float *dst, long long ntexels, int nch,
+                                      void *stream)
+{
+  if (ntexels <= 0) return 0;
+  const long long blocks = (ntexels + 255) / 256;
+  hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, ntexels, nch);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+
+// ---------------------------------------------------------------------------
+// to_screen_t (envutil_payload.cc:251-413), the put stage of the tethered
+// pipeline: every channel goes through lut_based_tf - in * 255.0f, clamp gate
+// [0, 255] (NATURAL spline: eval.h:2096-2104), linear interpolation between two
+// knots of the sRGB LUT (wl = 1 - t; s = c0 * wl; s += c1 * t), truncation to
+// uint32 - and the four bytes are packed A<<24 | B<<16 | G<<8 | R. Runs over
+// the float frame the render kernel just wrote (still in L2 / MALL for
+// screen-sized frames).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned screen_channel(const float *__restrict__ lut, float v)
+{
+  float c = v * 255.0f;
+  c = c < 0.0f ? 0.0f : c;
+  c = c > 255.0f ? 255.0f : c;
+  const float fl = floorf(c);
+  const float t = c - fl;
+  int i = (int)fl;
+  i = min(max(i, 0), 255);            // NaN input (undefined in the reference): stay in the table
+  const float wl = 1.0f - t;
+  float s = lut[i] * wl;
+  s = s + lut[i + 1] * t;
+  return (unsigned)s;
+}
+
+__global__ __launch_bounds__(256) void to_screen_kernel(const float *__restrict__ in,
+                                                        long long in_stride,
+                                                        unsigned *__restrict__ out,
+                                                        long long out_stride, int w, int nch,
+                                                        const float *__restrict__ lut)
+{
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= w) return;
+  const float *px = in + (long long)y * in_stride + (long long)x * nch;
+  const unsigned c1 = screen_channel(lut, px[0]);
+  unsigned word;
+  if (nch == 1) word = 0xFF000000u | (c1 << 16) | (c1 << 8) | c1;
+  else if (nch == 2) word = (screen_channel(lut, px[1]) << 24) | (c1 << 16) | (c1 << 8) | c1;
+  else {
+    const unsigned c2 = screen_channel(lut, px[1]), c3 = screen_channel(lut, px[2]);
+    const unsigned a = nch == 3 ? 0xFFu : screen_channel(lut, px[3]);
+    word = (a << 24) | (c3 << 16) | (c2 << 8) | c1;
+  }
+  out[(long long)y * out_stride + x] = word;
+}
+
+extern "C" int eu_launch_to_screen(const float *in, long long in_stride, unsigned *out,
+                                   long long out_stride, int w, int rows, int nch, const float *lut,
+                                   void *stream)
+{
+  if (w <= 0 || rows <= 0) return 0;
+  dim3 grid((unsigned)((w + 255) / 256), (unsigned)rows);
+  hipLaunchKernelGGL(to_screen_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, out,
+                     out_stride, w, nch, lut);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
