@@ -56,7 +56,8 @@ OUT_FLOAT, OUT_SRGBA8 = 0, 1
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libeu_hip.so")
+    # EU_HIP_LIB: another build of the library (build-time A/B experiments)
+    return os.environ.get("EU_HIP_LIB") or os.path.join(HERE, "lib", "libeu_hip.so")
 
 
 def build(force=False):

@@ -369,8 +369,15 @@ __device__ __forceinline__ void eu_eval2(const eu_src_dev &s, eu_f2 sx, eu_f2 sy
 // the kernel
 // ---------------------------------------------------------------------------
 
+// EU2_WAVES (build-time experiment): cap the registers for that many waves per SIMD
+#ifdef EU2_WAVES
+#define EU2_OCC __attribute__((amdgpu_waves_per_eu(EU2_WAVES, EU2_WAVES)))
+#else
+#define EU2_OCC
+#endif
+
 template <int NCH, int DEG, int PRJ, bool TWINE, bool PLANAR = false>
-__global__ __launch_bounds__(256) void eu_render2_kernel(const eu_render_params p)
+__global__ __launch_bounds__(256) EU2_OCC void eu_render2_kernel(const eu_render_params p)
 {
   // atanf range table in LDS (eu_math2.h): filled before any thread leaves
   __shared__ __attribute__((aligned(16))) float atab[EU_ATAN_TAB_FLOATS];

@@ -5,10 +5,11 @@ cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 make -s -C oracle _build/libeu_oracle.so
 for kv in ${VARIANTS}; do
   for w in ${WORKLOADS:-headline}; do
-    env $kv python bench.py --workload $w --steps ${STEPS:-20} --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/envab_${kv}_${w}.json
-    python - "$kv" "$w" <<'PY'
+    f="gpurun_out/envab_${kv//\//_}_${w}.json"
+    env $kv python bench.py --workload $w --steps ${STEPS:-20} --no-cpu-baseline 2>&1 | tail -1 > "$f"
+    python - "$kv" "$w" "$f" <<'PY'
 import json,sys
-d=json.loads(open(f"gpurun_out/envab_{sys.argv[1]}_{sys.argv[2]}.json").read())
+d=json.loads(open(sys.argv[3]).read())
 print(sys.argv[1], sys.argv[2], "kernel_ms", d['roofline']['kernel_ms'], "ms/step", d['ms_per_step'], "frac", d['roofline']['frac'])
 PY
   done
