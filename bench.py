@@ -55,6 +55,7 @@ WORKLOAD_TEXT = {
     "probe_bilinear": "DIAGNOSTIC 16384x8192 lat/lon -> 6x4096 cubemap, bilinear",
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+BAND_ROWS = 64          # multi-GPU tiling unit (eu_target.band_rows): two XCD units of the kernels
 
 
 class _DevBuf:
@@ -151,13 +152,16 @@ def main():
 
     args = ea.arguments(tprj, tw, th, thfov, yaw=ypr[0], pitch=ypr[1], roll=ypr[2],
                         spline_degree=degree, twine=twine)
-    # row strip of this rank (multiples of the 4-row tile height)
-    from envutil_amd.distributed import row_partition, gather_strips
-    r0, r1 = row_partition(th, world, rank, align=4)
+    # this rank's rows: interleaved bands of BAND_ROWS rows dealt round-robin
+    # (rows differ in cost - the polar cube faces take 1.7x the others - so
+    # contiguous strips would leave 8 GPUs at 5.6x, tools/strip_times.py)
+    from envutil_amd.distributed import gather_bands
+    band = (BAND_ROWS, world, rank) if world > 1 else None
+    r0, r1 = 0, ea.band_rows(th, BAND_ROWS, world, rank) if world > 1 else th
     out = torch.empty(((r1 - r0), tw, nch), device=dev, dtype=torch.float32)
     srcs = (C.c_void_p * len(sources))(*[x.handle for x in sources])
     nsrcs = len(sources)
-    tgt = args.target(nch, r0, r1, 0)
+    tgt = args.target(nch, r0, r1, 0, band)
 
     def step():
         rc = ea.lib().eu_hip_render(C.byref(tgt), srcs, nsrcs, C.c_void_p(out.data_ptr()),
@@ -193,14 +197,14 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        frame = gather_strips(dist, out, th, tw, nch, rank, world, dst=0, align=4)
+        frame = gather_bands(dist, out, th, tw, nch, rank, world, BAND_ROWS, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         gather_ms = 1e3 * (time.perf_counter() - tg)
         del frame
 
     # ---- kernel-only time with HIP events on the kernel's stream ------------
-    kernel_ms = ea.render_timed(args, sources, out.data_ptr(), max(a.steps, 5), nch, r0, r1)
+    kernel_ms = ea.render_timed(args, sources, out.data_ptr(), max(a.steps, 5), nch, r0, r1, band)
 
     # ---- the boundary with HOST buffers (never `value`): pixels in, pixels out ----
     # load = H2D of the source + prefilter/brace on the device; render_to_host =
@@ -267,7 +271,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": WORKLOAD_TEXT[a.workload], "name": a.workload,
                    "channels": nch, "spline_degree": degree, "twine": twine,
-                   "rows_per_gpu": r1 - r0, "tiling": f"rows/{world}",
+                   "rows_per_gpu": r1 - r0,
+                   "tiling": "whole frame" if world == 1 else f"bands of {BAND_ROWS} rows, round-robin over {world} ranks",
                    "gather_ms_untimed": None if gather_ms is None else round(gather_ms, 3),
                    "setup_s": round(t_setup, 2),
                    "host_boundary": {"source_load_s": round(t_load, 3),

@@ -49,7 +49,8 @@ class Target(C.Structure):
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("stage", C.c_int32),
                 ("crop_x0", C.c_int32), ("crop_y0", C.c_int32),
                 ("crop_w", C.c_int32), ("crop_h", C.c_int32),
-                ("out_format", C.c_int32)]
+                ("out_format", C.c_int32),
+                ("band_rows", C.c_int32), ("band_count", C.c_int32), ("band_index", C.c_int32)]
 
 
 OUT_FLOAT, OUT_SRGBA8 = 0, 1
@@ -122,6 +123,8 @@ def lib():
     L.eu_hip_source_release.argtypes = [vp]
     L.eu_hip_render.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
     L.eu_hip_render_timed.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
+    L.eu_hip_band_rows.argtypes = [i32, i32, i32, i32]
+    L.eu_hip_band_rows.restype = i32
     L.eu_hip_malloc.argtypes = [vp, C.c_size_t]
     L.eu_hip_free.argtypes = [vp]
     L.eu_hip_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
@@ -314,7 +317,9 @@ class arguments:
             self.twine_spread = make_spread(twine, twine, twine_width, twine_sigma,
                                             twine_threshold)
 
-    def target(self, nchannels, row_begin=0, row_end=None, stage=0):
+    def target(self, nchannels, row_begin=0, row_end=None, stage=0, band=None):
+        """band = (band_rows, band_count, band_index): this call renders the
+        interleaved row bands of one part (eu_target.band_*); rows are local"""
         t = Target()
         t.projection = self.projection
         t.width, t.height = self.width, self.height
@@ -328,8 +333,12 @@ class arguments:
             x0, x1, y0, y1 = self.p_crop
             t.crop_x0, t.crop_y0, t.crop_w, t.crop_h = x0, y0, x1 - x0, y1 - y0
         t.out_format = OUT_SRGBA8 if self.tethered else OUT_FLOAT
+        nrows = self.out_height
+        if band is not None and band[1] > 1:
+            t.band_rows, t.band_count, t.band_index = band
+            nrows = band_rows(self.out_height, *band)
         t.row_begin = row_begin
-        t.row_end = self.out_height if row_end is None else row_end
+        t.row_end = nrows if row_end is None else row_end
         t.stage = stage
         return t
 
@@ -342,7 +351,19 @@ class arguments:
         return self.p_crop[3] - self.p_crop[2] if self.store_cropped else self.height
 
 
-def render(args, sources, nchannels=None, row_begin=0, row_end=None, stage=0, out=None):
+def band_rows(height, rows, count, index):
+    """local rows of part `index` when `height` rows are dealt out in bands of
+    `rows` rows to `count` parts (eu_hip_band_rows)"""
+    return lib().eu_hip_band_rows(height, rows, count, index)
+
+
+def band_frame_rows(height, rows, count, index):
+    """frame row of every local row of that part, in order (numpy int64)"""
+    y = np.arange(height)
+    return y[(y // rows) % count == index] if count > 1 else y
+
+
+def render(args, sources, nchannels=None, row_begin=0, row_end=None, stage=0, out=None, band=None):
     """zimt::process(shape, get, act, put, bill) for rows [row_begin, row_end):
     returns (rows, width, nch) float32 on the host - (rows, width) uint32
     sRGBA8 words for a tethered job; width/rows are those of the crop window
@@ -350,7 +371,7 @@ def render(args, sources, nchannels=None, row_begin=0, row_end=None, stage=0, ou
     if not isinstance(sources, (list, tuple)):
         sources = [sources]
     nch = nchannels or sources[0].fct.nchannels
-    t = args.target(nch, row_begin, row_end, stage)
+    t = args.target(nch, row_begin, row_end, stage, band)
     rows = t.row_end - t.row_begin
     w = args.out_width
     if args.tethered:
@@ -368,13 +389,13 @@ def render(args, sources, nchannels=None, row_begin=0, row_end=None, stage=0, ou
 
 
 def render_timed(args, sources, out_dev_ptr, iters, nchannels=None, row_begin=0,
-                 row_end=None):
+                 row_end=None, band=None):
     """kernel-only timing with HIP events on the library's stream; the output
     stays in HBM at out_dev_ptr. Returns mean milliseconds per launch."""
     if not isinstance(sources, (list, tuple)):
         sources = [sources]
     nch = nchannels or sources[0].fct.nchannels
-    t = args.target(nch, row_begin, row_end, 0)
+    t = args.target(nch, row_begin, row_end, 0, band)
     arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
     ms = C.c_float()
     och = 1 if args.tethered else nch

@@ -273,6 +273,24 @@ int ensure_planar(eu_source *s)
 inline int frame_w(const eu_target *t) { return t->crop_w > 0 ? t->crop_w : t->width; }
 inline int frame_h(const eu_target *t) { return t->crop_w > 0 ? t->crop_h : t->height; }
 
+// rows of the processed frame that belong to this call (interleaved bands)
+int local_rows(int height, int band_rows, int band_count, int band_index)
+{
+  if (band_count <= 1) return height;
+  const int nb = (height + band_rows - 1) / band_rows;       // bands of the frame
+  int rows = 0;
+  for (int b = band_index; b < nb; b += band_count)
+    rows += std::min(band_rows, height - b * band_rows);
+  return rows;
+}
+
+int band_shift_of(int band_rows)
+{
+  int sh = 0;
+  while ((1 << sh) < band_rows) sh++;
+  return sh;
+}
+
 int check_target(const eu_target *t)
 {
   if (t->nchannels < 1 || t->nchannels > 4) return fail(EU_ERR_ARGUMENT, "target channels must be 1..4");
@@ -281,7 +299,14 @@ int check_target(const eu_target *t)
                         (long long)t->crop_x0 + t->crop_w > t->width ||
                         (long long)t->crop_y0 + t->crop_h > t->height)))
     return fail(EU_ERR_ARGUMENT, "crop window outside the target");
-  if (t->row_begin < 0 || t->row_end > frame_h(t) || t->row_begin > t->row_end)
+  if (t->band_count > 1) {
+    if (t->band_rows < 4 || (t->band_rows & (t->band_rows - 1)))
+      return fail(EU_ERR_ARGUMENT, "band_rows must be a power of two >= 4");
+    if (t->band_index < 0 || t->band_index >= t->band_count)
+      return fail(EU_ERR_ARGUMENT, "band_index outside [0, band_count)");
+  }
+  if (t->row_begin < 0 || t->row_begin > t->row_end ||
+      t->row_end > local_rows(frame_h(t), t->band_rows, t->band_count, t->band_index))
     return fail(EU_ERR_ARGUMENT, "row range outside the target");
   if (t->ntaps < 0 || t->ntaps > EU_MAX_TAPS || (t->ntaps > 0 && !t->taps))
     return fail(EU_ERR_ARGUMENT, "bad twining tap table");
@@ -316,6 +341,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   {
     eu_target tk = *t;
     tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
+    tk.band_rows = 0; tk.band_count = 0; tk.band_index = 0;     // the tables cover the whole frame
     unsigned char *q = key.data();
     memcpy(q, &tk, sizeof tk); q += sizeof tk;
     double fo[3] = { s->fct.yaw, s->fct.pitch, s->fct.roll };
@@ -349,6 +375,9 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   memset(p, 0, sizeof *p);
   p->width = frame_w(t); p->height = frame_h(t);
   p->row_begin = t->row_begin; p->row_end = t->row_end;
+  if (t->band_count > 1) {
+    p->band_shift = band_shift_of(t->band_rows); p->band_count = t->band_count; p->band_index = t->band_index;
+  }
   p->form = form; p->norm_mode = norm_mode;
   p->twine = twine; p->ntaps = t->ntaps; p->stage = t->stage; p->nch = s->nch;
   p->nch_out = t->nchannels;
@@ -369,6 +398,7 @@ struct multi_params {
   float *out;
   long long out_stride;
   int tiles_x, tiles_y;
+  int band_shift, band_count, band_index;
 };
 
 // fuse() for several facets (envutil_payload.cc:2139-2180, :2240-2281): one
@@ -389,6 +419,7 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   {
     eu_target tk = *t;
     tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
+    tk.band_rows = 0; tk.band_count = 0; tk.band_index = 0;     // the tables cover the whole frame
     unsigned char *q = key.data();
     memcpy(q, &tk, sizeof tk); q += sizeof tk;
     memcpy(q, &nsrc, sizeof(int)); q += sizeof(int);
@@ -437,6 +468,9 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   HIPCHK(hipStreamSynchronize(g.stream));
   memset(p, 0, sizeof *p);
   p->width = frame_w(t); p->height = frame_h(t); p->row_begin = t->row_begin; p->row_end = t->row_end;
+  if (t->band_count > 1) {
+    p->band_shift = band_shift_of(t->band_rows); p->band_count = t->band_count; p->band_index = t->band_index;
+  }
   p->form = g.mplan_form; p->norm_mode = g.mplan_norm; p->twine = twine; p->ntaps = t->ntaps;
   p->nch = t->nchannels; p->nfct = nsrc; p->plus = (t->nchannels == 2 || t->nchannels == 4);
   p->col = g.mcol; p->row = g.mrow; p->taps = g.mtaps; p->srcs = g.msrc;
@@ -703,6 +737,12 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
                           hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return EU_OK;
+}
+
+int eu_hip_band_rows(int height, int band_rows, int band_count, int band_index)
+{
+  if (height < 0 || (band_count > 1 && (band_rows < 1 || band_index < 0 || band_index >= band_count))) return 0;
+  return local_rows(height, band_rows, band_count, band_index);
 }
 
 int eu_hip_sync(void)

@@ -56,6 +56,17 @@ struct eu_src_dev {
   float wm[(EU_MAX_DEGREE + 1) * (EU_MAX_DEGREE + 1)];  // weight matrix [c][row]
 };
 
+// frame row of local row yl when the frame is dealt out in bands of
+// (1 << shift) rows, band b going to part b % count
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int eu_frame_row(int yl, int shift, int count, int index)
+{
+  if (count <= 1) return yl;
+  return ((((yl >> shift) * count) + index) << shift) | (yl & ((1 << shift) - 1));
+}
+
 struct eu_render_params {
   int width, height, row_begin, row_end;
   int form, norm_mode, twine, ntaps, stage, nch;   // nch: channels of the source
@@ -68,6 +79,9 @@ struct eu_render_params {
   int tiles_x, tiles_y;      // grid of 64x4 tiles
   int unit_rows;             // tile rows per XCD unit (eu_render2.hip)
   int direct;                // 1: never stage through LDS (A/B switch, EU_HIP_DIRECT=1)
+  // interleaved row bands (multi-GPU tiling, eu_target.band_*): local row yl of this
+  // call is frame row eu_frame_row(yl, ...); band_count <= 1: identity
+  int band_shift, band_count, band_index;
   eu_src_dev src;
 };
 

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void eu_diag_kernel(const eu_render_params p,
   const int x = tile_x * EU_TILE_W + lane;
   const int y = p.row_begin + tile_y * EU_TILE_H + wrow;
   if (y >= p.row_end || x >= p.width) return;
-  const float *rowt = p.row + (long long)y * EU_ROW_FLOATS;
+  const float *rowt = p.row + (long long)eu_frame_row(y, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
   float rx, ry, rz;
   eu_stepper(p, p.col, p.col + p.width, rowt, x, rx, ry, rz);
   asm volatile("" :: "v"(rx), "v"(ry), "v"(rz));

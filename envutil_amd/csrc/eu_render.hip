@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
   const int y = p.row_begin + tile_y * EU_TILE_H + wrow;   // wave-uniform
   if (y >= p.row_end || x >= p.width) return;
 
-  const float *rowt = p.row + (long long)y * EU_ROW_FLOATS;
+  const float *rowt = p.row + (long long)eu_frame_row(y, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
   const float *col0 = p.col, *col1 = p.col + p.width;
   float rx, ry, rz;
   eu_stepper(p, col0, col1, rowt, x, rx, ry, rz);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void eu_render_lds_kernel(const eu_render_para
 
   float rx = 0.0f, ry = 0.0f, rz = 1.0f;
   if (active) {
-    const float *rowt = p.row + (long long)y * EU_ROW_FLOATS;
+    const float *rowt = p.row + (long long)eu_frame_row(y, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
     eu_stepper(p, p.col, p.col + p.width, rowt, x, rx, ry, rz);
   }
   float sx = 0.0f, sy = 0.0f;

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) EU2_OCC void eu_render2_kernel(const eu_render
   const int xbc = vb ? xb : xa;
   const eu_src_dev &s = p.src;
 
-  eu_cptr rowt = (eu_cptr)(p.row + (long long)y * EU_ROW_FLOATS);
+  eu_cptr rowt = (eu_cptr)(p.row + (long long)eu_frame_row(y, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS);
   const eu_ray2 r00 = eu_rays2(p.form, p.norm_mode, rowt, p.col, p.col + p.width, xa, xbc);
 
   float pxa[NCH], pxb[NCH];
@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_para
   // rays: the two pixels share the column value and differ in the row constants
   eu_ray2 r;
   {
-    const float *ra = p.row + (long long)yac * EU_ROW_FLOATS, *rb = p.row + (long long)ybc * EU_ROW_FLOATS;
+    const float *ra = p.row + (long long)eu_frame_row(yac, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
+    const float *rb = p.row + (long long)eu_frame_row(ybc, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
     const float c0 = p.col[xc];
     const eu_f2 A0 = { ra[0], rb[0] }, A1 = { ra[1], rb[1] }, A2 = { ra[2], rb[2] };
     const eu_f2 B0 = { ra[3], rb[3] }, B1 = { ra[4], rb[4] }, B2 = { ra[5], rb[5] };

@@ -30,6 +30,7 @@ struct eu_multi_params {
   float *out;
   long long out_stride;
   int tiles_x, tiles_y;
+  int band_shift, band_count, band_index;   // eu_frame_row
 };
 
 struct eu_pix { int x, y; };
@@ -38,7 +39,7 @@ struct eu_pix { int x, y; };
 __device__ __forceinline__ void eu_multi_ray(const eu_multi_params &p, int f, int variant,
                                              const eu_pix &px, float &rx, float &ry, float &rz)
 {
-  const float *rowt = p.row + ((long long)f * p.height + px.y) * EU_ROW_FLOATS
+  const float *rowt = p.row + ((long long)f * p.height + eu_frame_row(px.y, p.band_shift, p.band_count, p.band_index)) * EU_ROW_FLOATS
                       + (variant == 2 ? EU_ROW_VARIANT : 0);
   const float *ca = variant == 1 ? p.col + 2 * p.width : p.col;
   eu_stepper(p.form, p.norm_mode, ca, ca + p.width, rowt, px.x, rx, ry, rz);

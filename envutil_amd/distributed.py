@@ -47,3 +47,48 @@ def gather_strips(dist, strip, height, width, nch, rank, world_size, dst=0, alig
     if strip.shape[0] > 0:
         dist.send(strip.contiguous(), dst=dst)
     return None
+
+
+# ---- interleaved row bands (eu_target.band_*) -----------------------------------
+# Rows of a frame can differ in cost (the polar faces of a cubemap target take
+# 1.7x the others: contiguous strips leave 8 GPUs at 5.6x, tools/strip_times.py).
+# Dealing bands of rows round-robin gives every rank a slice of every region.
+
+def band_frame_rows(height, band_rows, world_size, rank):
+    """frame rows of `rank`, in the order of its local rows (torch int64, CPU)"""
+    import torch
+    y = torch.arange(height, dtype=torch.int64)
+    if world_size <= 1:
+        return y
+    return y[(y // band_rows) % world_size == rank]
+
+
+def band_local_rows(height, band_rows, world_size, rank):
+    return int(band_frame_rows(height, band_rows, world_size, rank).numel())
+
+
+def gather_bands(dist, strip, height, width, nch, rank, world_size, band_rows, dst=0):
+    """collect every rank's compacted (local_rows, width, nch) band set on `dst`
+    and put the rows where they belong; returns the frame there, None elsewhere"""
+    import torch
+    if world_size == 1:
+        return strip
+    if rank == dst:
+        frame = torch.empty((height, width, nch), dtype=strip.dtype, device=strip.device)
+        frame[band_frame_rows(height, band_rows, world_size, rank).to(strip.device)] = strip
+        bufs, reqs = {}, []
+        for r in range(world_size):
+            if r == dst:
+                continue
+            n = band_local_rows(height, band_rows, world_size, r)
+            if n:
+                bufs[r] = torch.empty((n, width, nch), dtype=strip.dtype, device=strip.device)
+                reqs.append(dist.irecv(bufs[r], src=r))
+        for q in reqs:
+            q.wait()
+        for r, b in bufs.items():
+            frame[band_frame_rows(height, band_rows, world_size, r).to(strip.device)] = b
+        return frame
+    if strip.shape[0] > 0:
+        dist.send(strip.contiguous(), dst=dst)
+    return None

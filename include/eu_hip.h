@@ -103,7 +103,20 @@ typedef struct eu_target {
    * pipeline writing args.p_screen_data (envutil_payload.cc:251-413, :524-530);
    * the output buffer is then uint32 and strides still count bytes.          */
   int32_t out_format;
+  /* Multi-GPU tiling by INTERLEAVED row bands (load balance: rows differ in
+   * cost, e.g. the polar faces of a cubemap target take 1.7x the others): the
+   * frame's rows are cut into bands of band_rows rows (a power of two >= 4),
+   * band b belongs to part b % band_count, and this call renders the bands of
+   * part band_index, compacted in order: local row l is frame row
+   * ((l / band_rows) * band_count + band_index) * band_rows + l % band_rows.
+   * row_begin/row_end and the output buffer then count LOCAL rows
+   * (eu_hip_band_rows tells how many there are). band_count <= 1: off.       */
+  int32_t band_rows, band_count, band_index;
 } eu_target;
+
+/* number of local rows of part band_index (see eu_target.band_*) in a frame of
+ * `height` rows; height itself when band_count <= 1 */
+int  eu_hip_band_rows(int height, int band_rows, int band_count, int band_index);
 
 enum { EU_OUT_FLOAT = 0, EU_OUT_SRGBA8 = 1 };
 

@@ -27,6 +27,28 @@ def test_row_partition_covers_without_overlap():
         row_partition(10, 2, 2)
 
 
+def test_band_rows_cover_without_overlap():
+    """interleaved bands: every frame row belongs to exactly one part; the
+    library's count (eu_hip_band_rows) agrees with the host-side row lists"""
+    import envutil_amd as ea
+    from envutil_amd.distributed import band_frame_rows, band_local_rows
+    for h in (1, 7, 100, 192, 24576, 24577, 1000):
+        for w in (1, 2, 3, 4, 8):
+            for br in (4, 8, 64):
+                parts = [band_frame_rows(h, br, w, r).numpy() for r in range(w)]
+                allrows = np.sort(np.concatenate(parts))
+                assert np.array_equal(allrows, np.arange(h))
+                for r in range(w):
+                    assert len(parts[r]) == ea.band_rows(h, br, w, r) == band_local_rows(h, br, w, r)
+                    assert np.array_equal(parts[r], ea.band_frame_rows(h, br, w, r))
+                    # local row l -> frame row, the kernel's formula (eu_device.h: eu_frame_row)
+                    l = np.arange(len(parts[r]))
+                    assert np.array_equal(((l // br) * w + r) * br + l % br, parts[r])
+                if w > 1 and h >= br * w:
+                    sizes = [len(p) for p in parts]
+                    assert max(sizes) - min(sizes) <= br
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -49,11 +71,21 @@ def _worker(rank, world, port, q):
         r0, r1 = row_partition(a.height, world, rank)
         strip = torch.from_numpy(jobs.oracle_render(a, o, row_begin=r0, row_end=r1, nthreads=2))
         frame = gather_strips(dist, strip, a.height, a.width, 3, rank, world)
+        # the same frame dealt out in interleaved bands of 8 rows (eu_target.band_*)
+        from envutil_amd.distributed import band_frame_rows, gather_bands
+        rows = band_frame_rows(a.height, 8, world, rank).numpy()
+        starts = rows[::8]
+        bands = [jobs.oracle_render(a, o, row_begin=int(s), row_end=int(min(s + 8, a.height)), nthreads=2)
+                 for s in starts]
+        mine = torch.from_numpy(np.concatenate(bands))
+        assert mine.shape[0] == ea.band_rows(a.height, 8, world, rank)
+        frame2 = gather_bands(dist, mine, a.height, a.width, 3, rank, world, 8)
         if rank == 0:
             whole = jobs.oracle_render(a, jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img, 3), nthreads=2)
-            q.put(bool((frame.numpy().view(np.uint32) == whole.view(np.uint32)).all()))
+            q.put(bool((frame.numpy().view(np.uint32) == whole.view(np.uint32)).all()) and
+                  bool((frame2.numpy().view(np.uint32) == whole.view(np.uint32)).all()))
         else:
-            q.put(frame is None)
+            q.put(frame is None and frame2 is None)
     finally:
         dist.destroy_process_group()
 

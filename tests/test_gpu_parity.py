@@ -373,3 +373,34 @@ def test_tethered_multi_facet_and_repix():
     a = ea.arguments(ea.RECTILINEAR, 120, 90, 80.0, spline_degree=1, tethered=True)
     got, ref = ea.render(a, g, 4), jobs.oracle_render(a, o, nch=4)
     assert np.array_equal(got, ref) and (got >> 24 == 255).all()
+
+
+# ---- interleaved row bands (multi-GPU tiling) -------------------------------------
+
+@pytest.mark.parametrize("world,band", [(2, 4), (3, 8), (8, 4)])
+def test_band_parts_assemble_the_frame(latlon, world, band):
+    """eu_target.band_*: every part's compacted rows, put back at their frame
+    rows, give the oracle's frame bit for bit (packed, general and multi kernels)"""
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], 3)
+    jobs_ = [(ea.arguments(ea.CUBEMAP, 40, 240, 90.0, yaw=3, spline_degree=3), g, o, 3),
+             (ea.arguments(ea.FISHEYE, 90, 101, 180.0, spline_degree=3, twine=2), g, o, 3)]
+    os_, gs = facet_set(euo.RECTILINEAR, 72, 72, 95.0, 4, 1, seed=3)
+    jobs_.append((ea.arguments(ea.SPHERICAL, 120, 75, 360.0, spline_degree=1), gs, os_, 4))
+    for a, gg, oo, nch in jobs_:
+        ref = jobs.oracle_render(a, oo)
+        frame = np.full_like(ref, np.nan)
+        for part in range(world):
+            rows = ea.band_frame_rows(a.height, band, world, part)
+            got = ea.render(a, gg, nch, band=(band, world, part))
+            assert got.shape[0] == len(rows) == ea.band_rows(a.height, band, world, part)
+            frame[rows] = got
+        assert_bits(frame, ref, f"bands {world}x{band} prj {a.projection}")
+    # local row ranges inside a part
+    a = jobs_[0][0]
+    whole = ea.render(a, g, 3, band=(band, world, 1))
+    n = whole.shape[0]
+    part = np.concatenate([ea.render(a, g, 3, 0, n // 2, band=(band, world, 1)),
+                           ea.render(a, g, 3, n // 2, n, band=(band, world, 1))])
+    assert_bits(part, whole, "row ranges of a band part")
+    with pytest.raises(ea.EuError):
+        ea.render(a, g, 3, band=(6, world, 0))            # not a power of two
