@@ -20,8 +20,7 @@ extern "C" int eu_launch_render2(const eu_render_params *p, void *stream);
 extern "C" int eu_launch_to_screen(const float *in, long long in_stride, unsigned *out,
                                    long long out_stride, int w, int rows, int nch, const float *lut,
                                    void *stream);
-extern "C" int eu_launch_deinterleave(const float *src, float *dst, long long ntexels, int nch,
-                                      void *stream);
+
 extern "C" int eu_verify_const_div(float c, float limit, void *stream);
 extern "C" int eu_launch_selftest(unsigned long long seed, int blocks, int iters,
                                   unsigned long long *bad_dev, void *stream);
@@ -42,8 +41,6 @@ struct eu_source {
   float *dev;            // braced container in HBM
   size_t nfloats;
   eu_src_dev sd;
-  float *planar = nullptr;   // derived channel-planar copy (lazily built, dropped when the
-                             // container is handed out for writing)
 };
 
 namespace {
@@ -234,41 +231,6 @@ void source_bcs(const eu_facet *f, int *bc0, int *bc1)
     *bc0 = EU_BC_PERIODIC;
 }
 
-void drop_planar(eu_source *s)
-{
-  if (s->planar) { (void)hipStreamSynchronize(g.stream); (void)hipFree(s->planar); }
-  s->planar = nullptr;
-  s->sd.planar = nullptr;
-}
-
-// Channel-planar copy for the packed kernel's cubic / quadratic taps of 3- and
-// 4-channel lat/lon and cubemap sources. An A/B variant (EU_HIP_PLANAR=1): a tap
-// row of one channel is one 16-byte load, but the three planes are three address
-// streams - measured 1.50 ms against 1.35 ms on the headline job, 1.23 against
-// 1.27 ms with a cubemap source. Off by default.
-int ensure_planar(eu_source *s)
-{
-  static const bool on = [] { const char *e = getenv("EU_HIP_PLANAR"); return e && e[0] == '1'; }();
-  const int prj = s->fct.projection;
-  const bool wanted = on && s->nch >= 3 && (s->degree == 2 || s->degree == 3) && !s->fct.has_lcp &&
-                      (prj == EU_SPHERICAL || prj == EU_CUBEMAP || prj == EU_BIATAN6);
-  if (!wanted) { if (s->planar) drop_planar(s); return EU_OK; }
-  if (s->planar) return EU_OK;
-  const long long ntex = (long long)(s->nfloats / (size_t)s->nch);
-  if (hipMalloc((void **)&s->planar, s->nfloats * sizeof(float)) != hipSuccess) {
-    (void)hipGetLastError();
-    s->planar = nullptr;      // no room: the interleaved container serves
-    return EU_OK;
-  }
-  if (eu_launch_deinterleave(s->dev, s->planar, ntex, s->nch, g.stream))
-    return fail(EU_ERR_NO_DEVICE, "deinterleave launch failed");
-  HIPCHK(hipStreamSynchronize(g.stream));   // renders may run on the caller's stream
-  const eu_container &g0 = s->geom;
-  s->sd.planar = s->planar + ((size_t)g0.left[1] * g0.shape[0] + g0.left[0]);
-  s->sd.plane_stride = ntex;
-  return EU_OK;
-}
-
 // the processed frame: the whole target or its crop window (store_cropped)
 inline int frame_w(const eu_target *t) { return t->crop_w > 0 ? t->crop_w : t->width; }
 inline int frame_h(const eu_target *t) { return t->crop_w > 0 ? t->crop_h : t->height; }
@@ -328,7 +290,6 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   eu_source *s = srcs[0];
   if (!s) return fail(EU_ERR_HANDLE, "null source");
   { int rc0 = check_target(t); if (rc0) return rc0; }
-  { int rc0 = ensure_planar(s); if (rc0) return rc0; }
   if (row_stride_bytes % sizeof(float))
     return fail(EU_ERR_ARGUMENT, "row stride must be a multiple of 4 bytes");
   const bool twine = t->ntaps > 0;
@@ -643,9 +604,6 @@ int eu_hip_source_alloc(const eu_facet *fct, int spline_degree, int support_min,
 int eu_hip_source_device_ptr(const eu_source *src, void **dev_ptr, size_t *nfloats)
 {
   if (!src) return fail(EU_ERR_HANDLE, "null source");
-  // the caller may write the container through this pointer (broadcast of the
-  // coefficients): derived copies are rebuilt at the next render
-  drop_planar(const_cast<eu_source *>(src));
   if (dev_ptr) *dev_ptr = src->dev;
   if (nfloats) *nfloats = src->nfloats;
   return EU_OK;
@@ -670,7 +628,6 @@ int eu_hip_source_info(const eu_source *src, eu_container *geom, int *nch)
 int eu_hip_source_release(eu_source *src)
 {
   if (!src) return EU_OK;
-  drop_planar(src);
   if (src->dev) (void)hipFree(src->dev);
   delete src;
   return EU_OK;

@@ -26,11 +26,6 @@ enum { EU_NORM_NONE = 0, EU_NORM_DIV = 1, EU_NORM_CYL = 2 };
 struct eu_src_dev {
   const float *base;         // core origin inside the braced container
   long long es0, es1;        // strides in float elements (eval.h:1865)
-  // derived channel-planar copy of the container (same geometry, one plane per
-  // channel), core origin of plane 0; null: none. A tap row of one channel is
-  // 16 contiguous bytes there - fewer cache lines per quad of lanes
-  const float *planar;
-  long long plane_stride;    // floats between planes; rows are es1 / nch floats apart
   int prj, nch, degree;
   int gate0, gate1;          // 0 clamp, 1 mirror, 2 periodic (eval.h:2039-2164)
   float lower0, upper0, lower1, upper1;

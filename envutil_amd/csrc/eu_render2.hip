@@ -111,35 +111,6 @@ __device__ __forceinline__ void eu_accumulate1(PTR p0, STRIDE es1,
   }
 }
 
-// the same weighted sum from the channel-planar copy: a tap row of one channel
-// is 4 consecutive floats (one 16-byte load); operations and their order are
-// those of eu_accumulate1
-template <int NCH, int DEG>
-__device__ __forceinline__ void eu_accumulate_planar(const float *p0, long long prow,
-                                                     long long pstride, const float *wx,
-                                                     const float *wy, float *out)
-{
-  constexpr int order = DEG + 1;
-  float sum[NCH];
-#pragma unroll
-  for (int j = 0; j < order; j++) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const float *q = p0 + c * pstride + j * prow;
-      float t[order];
-#pragma unroll
-      for (int i = 0; i < order; i++) t[i] = q[i];
-      float r = t[0] * wx[0];
-#pragma unroll
-      for (int i = 1; i < order; i++) r = r + wx[i] * t[i];
-      if (j == 0) sum[c] = r * wy[0];
-      else sum[c] = sum[c] + r * wy[j];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; c++) out[c] = sum[c];
-}
-
 __device__ __forceinline__ float eu_gate1(float c, int kind, float lower, float upper)
 {
   return eu_gate(c, kind, lower, upper);
@@ -309,7 +280,7 @@ __device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r
 // both lanes: b-spline evaluation at (sx, sy); misses give 0
 // ---------------------------------------------------------------------------
 
-template <int NCH, int DEG, bool PLANAR = false>
+template <int NCH, int DEG>
 __device__ __forceinline__ void eu_eval2(const eu_src_dev &s, eu_f2 sx, eu_f2 sy, eu_i2 hit,
                                          float *pxa, float *pxb)
 {
@@ -341,18 +312,10 @@ __device__ __forceinline__ void eu_eval2(const eu_src_dev &s, eu_f2 sx, eu_f2 sy
   // the container, framed or not); its result is discarded
   const int ixa = hit.x ? (int)fx.x : DEG / 2, iya = hit.x ? (int)fy.x : DEG / 2;
   const int ixb = hit.y ? (int)fx.y : DEG / 2, iyb = hit.y ? (int)fy.y : DEG / 2;
-  if constexpr (PLANAR) {
-    const long long prow = s.es1 / NCH;
-    const float *pa = s.planar + (long long)(ixa - DEG / 2) + (long long)(iya - DEG / 2) * prow;
-    const float *pb = s.planar + (long long)(ixb - DEG / 2) + (long long)(iyb - DEG / 2) * prow;
-    eu_accumulate_planar<NCH, DEG>(pa, prow, s.plane_stride, wxa, wya, pxa);
-    eu_accumulate_planar<NCH, DEG>(pb, prow, s.plane_stride, wxb, wyb, pxb);
-  } else {
-    const float *pa = s.base + (long long)(ixa - DEG / 2) * NCH + (long long)(iya - DEG / 2) * s.es1;
-    const float *pb = s.base + (long long)(ixb - DEG / 2) * NCH + (long long)(iyb - DEG / 2) * s.es1;
-    eu_accumulate1<NCH, DEG>(pa, s.es1, wxa, wya, tx.x, ty.x, pxa);
-    eu_accumulate1<NCH, DEG>(pb, s.es1, wxb, wyb, tx.y, ty.y, pxb);
-  }
+  const float *pa = s.base + (long long)(ixa - DEG / 2) * NCH + (long long)(iya - DEG / 2) * s.es1;
+  const float *pb = s.base + (long long)(ixb - DEG / 2) * NCH + (long long)(iyb - DEG / 2) * s.es1;
+  eu_accumulate1<NCH, DEG>(pa, s.es1, wxa, wya, tx.x, ty.x, pxa);
+  eu_accumulate1<NCH, DEG>(pb, s.es1, wxb, wyb, tx.y, ty.y, pxb);
   // environment::eval brighten (environment.h:1821-1842), zero on a miss
   constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
   const bool bright = s.brighten != 1.0f;
@@ -376,7 +339,7 @@ __device__ __forceinline__ void eu_eval2(const eu_src_dev &s, eu_f2 sx, eu_f2 sy
 #define EU2_OCC
 #endif
 
-template <int NCH, int DEG, int PRJ, bool TWINE, bool PLANAR = false>
+template <int NCH, int DEG, int PRJ, bool TWINE>
 __global__ __launch_bounds__(256) EU2_OCC void eu_render2_kernel(const eu_render_params p)
 {
   // atanf range table in LDS (eu_math2.h): filled before any thread leaves
@@ -405,7 +368,7 @@ __global__ __launch_bounds__(256) EU2_OCC void eu_render2_kernel(const eu_render
   if constexpr (!TWINE) {
     eu_f2 sx, sy;
     const eu_i2 hit = eu_coord2<PRJ>(s, r00, sx, sy, atab);
-    eu_eval2<NCH, DEG, PLANAR>(s, sx, sy, hit, pxa, pxb);
+    eu_eval2<NCH, DEG>(s, sx, sy, hit, pxa, pxb);
   } else {
     // deriv_stepper (stepper.h:1591-1715) + twine_t::eval (twining.h:128-263)
     const eu_ray2 r10 = eu_rays2(p.form, p.norm_mode, rowt, p.col + 2 * p.width,
@@ -425,7 +388,7 @@ __global__ __launch_bounds__(256) EU2_OCC void eu_render2_kernel(const eu_render
       eu_f2 sx, sy;
       const eu_i2 hit = eu_coord2<PRJ>(s, rk, sx, sy, atab);
       float qa[NCH], qb[NCH];
-      eu_eval2<NCH, DEG, PLANAR>(s, sx, sy, hit, qa, qb);
+      eu_eval2<NCH, DEG>(s, sx, sy, hit, qa, qb);
 #pragma unroll
       for (int c = 0; c < NCH; c++) { pxa[c] = pxa[c] + cw * qa[c]; pxb[c] = pxb[c] + cw * qb[c]; }
     }
@@ -482,8 +445,19 @@ __global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_para
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int x = tile_x * EU3_TW + (threadIdx.x & 31);
-  const int ya = p.row_begin + tile_y * EU3_TH + (threadIdx.x >> 5), yb = ya + 8;
+  // lane -> pixel inside the 32x16 tile. Staged: rows of 32. Direct gathers: the
+  // four lanes the memory pipe serves together (a quad) form a 2x2 pixel block,
+  // which touches about the same number of cache lines for every orientation of
+  // the mapping; a wave covers 32x2 pixels either way.
+  int lx, ly;
+  if constexpr (STAGE) { lx = threadIdx.x & 31; ly = threadIdx.x >> 5; }
+  else {
+    const int l = threadIdx.x & 63;
+    lx = ((l >> 2) << 1) | (l & 1);
+    ly = ((threadIdx.x >> 6) << 1) | ((l >> 1) & 1);
+  }
+  const int x = tile_x * EU3_TW + lx;
+  const int ya = p.row_begin + tile_y * EU3_TH + ly, yb = ya + 8;
   const bool la = x < p.width && ya < p.row_end, lb = x < p.width && yb < p.row_end;
   const int xc = x < p.width ? x : p.width - 1;
   const int yac = ya < p.row_end ? ya : p.row_end - 1, ybc = yb < p.row_end ? yb : p.row_end - 1;
@@ -621,6 +595,7 @@ __global__ __launch_bounds__(256, 4) void eu_render3_kernel(const eu_render_para
   }
 }
 
+
 template <int NCH, int DEG, int PRJ>
 static int launch2_ndp(const eu_render_params &p, hipStream_t st)
 {
@@ -639,14 +614,6 @@ static int launch2_ndp(const eu_render_params &p, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, p.unit_rows)), block(256);
-  if constexpr (NCH >= 3 && DEG >= 2) {
-    // the channel-planar copy of the source, when the library made one
-    if (p.src.planar) {
-      if (p.twine) hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, true, true>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, false, true>), grid, block, 0, st, p);
-      return hipGetLastError() == hipSuccess ? 0 : -1;
-    }
-  }
   if (p.twine) hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((eu_render2_kernel<NCH, DEG, PRJ, false>), grid, block, 0, st, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -501,30 +501,6 @@ extern "C" int eu_verify_const_div(float c, float limit, void *stream)
 
 
 // ---------------------------------------------------------------------------
-// channel-planar copy of an interleaved container (derived data for the packed
-// cubic kernel): dst[c][i] = src[i * nch + c]
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void deinterleave_kernel(const float *__restrict__ src,
-                                                           float *__restrict__ dst,
-                                                           long long ntexels, int nch)
-{
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= ntexels) return;
-  for (int c = 0; c < nch; c++) dst[(long long)c * ntexels + i] = src[i * nch + c];
-}
-
-extern "C" int eu_launch_deinterleave(const float *src, float *dst, long long ntexels, int nch,
-                                      void *stream)
-{
-  if (ntexels <= 0) return 0;
-  const long long blocks = (ntexels + 255) / 256;
-  hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     src, dst, ntexels, nch);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-
-// ---------------------------------------------------------------------------
 // to_screen_t (envutil_payload.cc:251-413), the put stage of the tethered
 // pipeline: every channel goes through lut_based_tf - in * 255.0f, clamp gate
 // [0, 255] (NATURAL spline: eval.h:2096-2104), linear interpolation between two
