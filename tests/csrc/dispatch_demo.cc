@@ -23,12 +23,26 @@ int main(int argc, char **argv)
   f.process_geometry();
   args.projection = CUBEMAP; args.width = tw; args.height = 6 * tw; args.hfov = M_PI / 2.0;
   args.yaw = 0.3; args.pitch = -0.2; args.roll = 0.1;
-  args.spline_degree = 3; args.twine = argc > 1 ? 2 : 0;
+  bool twine = false, screen = false, crop = false;
+  for (int i = 1; i < argc; i++) {
+    if (!std::strcmp(argv[i], "twine")) twine = true;
+    if (!std::strcmp(argv[i], "screen")) screen = true;     // tethered: packed sRGBA8 words
+    if (!std::strcmp(argv[i], "crop")) crop = true;         // PTO p-line crop
+  }
+  args.spline_degree = 3; args.twine = twine ? 2 : 0;
   args.facet_spec_v = { f };
   args.target_setup();
   args.twine_setup();
-  std::vector<float> out(size_t(args.width) * args.height * 3);
-  args.p_output = out.data();
+  int ow = args.width, oh = args.height;
+  if (crop) {
+    args.store_cropped = true;
+    args.p_crop_x0 = 5; args.p_crop_x1 = 60; args.p_crop_y0 = 30; args.p_crop_y1 = 301;
+    ow = args.p_crop_x1 - args.p_crop_x0; oh = args.p_crop_y1 - args.p_crop_y0;
+  }
+  // one 32-bit word per channel value (float) or per pixel (tethered)
+  std::vector<float> out(size_t(ow) * oh * (screen ? 1 : 3));
+  if (screen) { args.tethered = true; args.p_screen_data = out.data(); }
+  else args.p_output = out.data();
   const dispatch_base *dp = get_dispatch();
   int rc = dp->payload(3, args.twine ? 9 : 3, args.projection);
   std::printf("rc %d\n", rc);

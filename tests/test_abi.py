@@ -87,3 +87,34 @@ def test_argument_errors_do_not_abort(L):
     assert L.eu_hip_get_extent(99, 10, 10, 1.0, e.ctypes.data_as(C.c_void_p)) == -2
     assert L.eu_hip_container_geometry(99, 0, 0, 10, 10, None) == -2
     assert b"" != L.eu_hip_last_error()
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct of include/eu_hip.h, as gcc lays them
+    out, against the ctypes mirrors in envutil_amd/api.py"""
+    import subprocess
+    from envutil_amd import api
+    structs = {"eu_facet": api.Facet, "eu_container": api.Container, "eu_target": api.Target}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "eu_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} size %zu\\n", sizeof({name}));')
+        for fld, _ in cls._fields_:
+            lines.append(f'  printf("{name} {fld} %zu\\n", offsetof({name}, {fld}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    seen = 0
+    for ln in out:
+        if not ln:
+            continue
+        name, fld, val = ln.split()
+        cls = structs[name]
+        if fld == "size":
+            assert C.sizeof(cls) == int(val), (name, C.sizeof(cls), val)
+        else:
+            assert getattr(cls, fld).offset == int(val), (name, fld)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())

@@ -26,7 +26,10 @@ def build_demo():
 
 def fnv1a(a):
     h = 1469598103934665603
-    for u in np.ascontiguousarray(a, np.float32).view(np.uint32).ravel().tolist():
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint32:
+        a = a.astype(np.float32, copy=False).view(np.uint32)
+    for u in a.ravel().tolist():
         h = ((h ^ u) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     return f"{h:016x}"
 
@@ -57,4 +60,25 @@ def test_cpp_payload_matches_oracle(twine):
                      roll=math.degrees(0.1), spline_degree=3, twine=twine)
     # the demo passes radians straight through; the Python mirror converts degrees
     a.yaw, a.pitch, a.roll = math.degrees(0.3), math.degrees(-0.2), math.degrees(0.1)
+    assert fnv1a(jobs.oracle_render(a, o)) == got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [("crop",), ("screen",), ("crop", "screen", "twine")])
+def test_cpp_payload_crop_and_tethered(mode):
+    """args.store_cropped / args.tethered through the C++ mirror"""
+    import euo
+    import jobs
+    build_demo()
+    r = subprocess.run([EXE] + list(mode), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = r.stdout.split("fnv1a")[1].strip()
+    sw, sh, tw = 256, 128, 64
+    y, x, c = np.indices((sh, sw, 3))
+    img = (np.float32(0.5) + np.float32(0.25) * ((x * 7 + y * 13 + c * 29) % 97).astype(np.float32)
+           / np.float32(97.0)).astype(np.float32)
+    o = jobs.OracleSource(euo.SPHERICAL, sw, sh, 360.0, img, 3)
+    a = ea.arguments(ea.CUBEMAP, tw, 6 * tw, 90.0, yaw=math.degrees(0.3), pitch=math.degrees(-0.2),
+                     roll=math.degrees(0.1), spline_degree=3, twine=2 if "twine" in mode else 0,
+                     crop=(5, 60, 30, 301) if "crop" in mode else None, tethered="screen" in mode)
     assert fnv1a(jobs.oracle_render(a, o)) == got
