@@ -292,32 +292,9 @@ def main():
         import jobs
         cont = src.download()
         g, _ = src.info()
-        osrc = jobs.OracleSource.__new__(jobs.OracleSource)
-        s = euo.Source()
-        s.projection = sprj
-        s.hfov = math.radians(shfov)
-        s.width, s.height = sw, sh
-        s.window_width, s.window_height = sw, sh
-        s.brighten = 1.0
-        sp = euo.Spline()
-        sp.data = cont.ctypes.data_as(C.POINTER(C.c_float))
-        sp.shape[0], sp.shape[1] = g.shape[0], g.shape[1]
-        sp.stride[0], sp.stride[1] = 1, g.shape[0]
-        sp.left[0], sp.left[1] = g.left[0], g.left[1]
-        sp.right[0], sp.right[1] = g.right[0], g.right[1]
-        sp.core[0], sp.core[1] = g.core[0], g.core[1]
-        if sprj in (ea.CUBEMAP, ea.BIATAN6):
-            sp.bc[0] = sp.bc[1] = euo.REFLECT
-            m = ea.cubemap_metrics(sw)
-            s.refc_md = np.float32(m["refc_md"])
-            s.model_to_px = np.float32(m["model_to_px"])
-            s.section_px = m["section_px"]
-        else:
-            sp.bc[0], sp.bc[1] = jobs.source_bcs(sprj, math.radians(shfov))
-        sp.degree = degree
-        sp.nch = nch
-        s.spl = sp
-        osrc.s, osrc.nch, osrc.degree, osrc.container = s, nch, degree, cont
+        osrc = jobs.oracle_source_from_container(
+            sprj, sw, sh, shfov, cont, g, degree, nch,
+            ea.cubemap_metrics(sw) if sprj in (ea.CUBEMAP, ea.BIATAN6) else None)
         cores = os.cpu_count() or 1
         try:
             cores = len(os.sched_getaffinity(0))

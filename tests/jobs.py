@@ -97,6 +97,42 @@ class OracleSource:
         self.degree = spline_degree
 
 
+def oracle_source_from_container(prj, width, height, hfov_deg, container, geom, degree, nch,
+                                 cubemap_metrics=None):
+    """an OracleSource over a finished (braced, prefiltered) coefficient array, e.g. the
+    one a GPU source downloads: the oracle then evaluates exactly what the kernels read.
+    geom: envutil_amd Container (shape/left/right/core); cubemap_metrics: dict of
+    envutil_amd.cubemap_metrics for cubemap / biatan6 sources"""
+    o = OracleSource.__new__(OracleSource)
+    s = euo.Source()
+    s.projection = prj
+    s.hfov = math.radians(hfov_deg)
+    s.width, s.height = width, height
+    s.window_width, s.window_height = width, height
+    s.brighten = 1.0
+    s.step = euo.lib().euo_get_step(prj, width, height, s.hfov)
+    sp = euo.Spline()
+    sp.data = container.ctypes.data_as(C.POINTER(C.c_float))
+    sp.shape[0], sp.shape[1] = geom.shape[0], geom.shape[1]
+    sp.stride[0], sp.stride[1] = 1, geom.shape[0]
+    sp.left[0], sp.left[1] = geom.left[0], geom.left[1]
+    sp.right[0], sp.right[1] = geom.right[0], geom.right[1]
+    sp.core[0], sp.core[1] = geom.core[0], geom.core[1]
+    if prj in (euo.CUBEMAP, euo.BIATAN6):
+        sp.bc[0] = sp.bc[1] = euo.REFLECT
+        s.refc_md = np.float32(cubemap_metrics["refc_md"])
+        s.model_to_px = np.float32(cubemap_metrics["model_to_px"])
+        s.section_px = cubemap_metrics["section_px"]
+    else:
+        sp.bc[0], sp.bc[1] = source_bcs(prj, s.hfov)
+    sp.degree = degree
+    sp.nch = nch
+    s.spl = sp
+    o.s, o.nch, o.degree, o.container = s, nch, degree, container
+    o.bc = (sp.bc[0], sp.bc[1])
+    return o
+
+
 def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8, nch=None):
     """args: envutil_amd.arguments (only its plain fields are read); osrc: one
     OracleSource or a list of them (multi-facet job)"""
