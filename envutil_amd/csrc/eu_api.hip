@@ -367,7 +367,7 @@ struct multi_params {
 int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out_dev,
                 size_t row_stride_bytes, multi_params *p, int *degree)
 {
-  if (nsrc > 16) return fail(EU_ERR_UNSUPPORTED, "more than 16 facets per job not built yet");
+  if (nsrc > 64) return fail(EU_ERR_UNSUPPORTED, "more than 64 facets per job");
   { int rc0 = check_target(t); if (rc0) return rc0; }
   const eu_source *s0 = srcs[0];
   for (int f = 0; f < nsrc; f++) {

@@ -395,17 +395,15 @@ template <int NCH, int DEG>
 __device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
                                                float rz, float *px);
 
-// environment::eval for a target with out_n != NCH channels: inner evaluation,
-// repix, brighten on the OUTPUT layout (environment.h:1821-1842, :1859-1900).
-// px has room for 4 floats.
+// environment::eval behind the coordinate stage, for callers that already have
+// the source coordinate (the multi-facet synopsis computes it for the mask):
+// inner evaluation, repix, brighten on the OUTPUT layout (environment.h:1821-1842,
+// :1859-1900). px has room for 4 floats.
 template <int NCH, int DEG>
-__device__ __forceinline__ void eu_environment_repix(const eu_src_dev &s, int out_n, float rx,
-                                                     float ry, float rz, float *px)
+__device__ __forceinline__ void eu_environment_repix_at(const eu_src_dev &s, int out_n, bool hit,
+                                                        float sx, float sy, float *px)
 {
-  float sx, sy;
-  int face;
   float raw[NCH];
-  bool hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
   if (hit) {
     if constexpr (DEG >= 0) eu_bspline<NCH, DEG>(s, sx, sy, raw);
     else eu_bspline_generic<NCH>(s, sx, sy, raw);
@@ -421,12 +419,19 @@ __device__ __forceinline__ void eu_environment_repix(const eu_src_dev &s, int ou
 }
 
 template <int NCH, int DEG>
-__device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
-                                               float rz, float *px)
+__device__ __forceinline__ void eu_environment_repix(const eu_src_dev &s, int out_n, float rx,
+                                                     float ry, float rz, float *px)
 {
   float sx, sy;
   int face;
-  bool hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+  const bool hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+  eu_environment_repix_at<NCH, DEG>(s, out_n, hit, sx, sy, px);
+}
+
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_environment_at(const eu_src_dev &s, bool hit, float sx, float sy,
+                                                  float *px)
+{
   if (hit) {
     if constexpr (DEG >= 0) eu_bspline<NCH, DEG>(s, sx, sy, px);
     else eu_bspline_generic<NCH>(s, sx, sy, px);
@@ -440,6 +445,16 @@ __device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, fl
 #pragma unroll
     for (int c = 0; c < NCH; c++) px[c] = 0.0f;
   }
+}
+
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
+                                               float rz, float *px)
+{
+  float sx, sy;
+  int face;
+  const bool hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+  eu_environment_at<NCH, DEG>(s, hit, sx, sy, px);
 }
 
 // ---------------------------------------------------------------------------

@@ -13,12 +13,17 @@
 // so those decisions are wavefront ballots masked to 16-lane groups - the
 // reference's any_of/all_of, bit for bit.
 //
-// Facets whose evaluation differs between lanes are handled by a waterfall loop:
-// the facet index is made wave-uniform (readfirstlane) so that its parameters
-// come through the scalar cache, and the lanes that want it evaluate together.
+// The facets are walked by run-time loops (any count up to 64): the facet index
+// is wave-uniform, its parameters come through the scalar cache. The mask pass
+// computes every facet's source coordinate once; the coordinates (and, with
+// alpha, the z scores the layers are sorted by) of up to 16 facets stay in LDS,
+// one slot per thread, and the evaluation of the winning facet(s) starts from
+// them. Facets whose evaluation differs between lanes are handled by a waterfall
+// loop (readlane makes the index uniform, the lanes that want it go together).
 #include "eu_render_dev.h"
 
-#define EU_MULTI_MAXF 16
+#define EU_MULTI_MAXF 64     // facets per job (one mask bit each)
+#define EU_MULTI_KEEP 16     // facets whose coordinates are kept in LDS (3 KB each per workgroup)
 
 struct eu_multi_params {
   int width, height, row_begin, row_end;
@@ -65,21 +70,52 @@ __device__ __forceinline__ void eu_syn_ray(const eu_multi_params &p, int f, cons
 }
 
 #ifdef EU_MULTI_NCH
+// per-thread slots in dynamic LDS: [z | sx | sy][facet][256 threads]
+struct eu_slots {
+  float *z, *sx, *sy;        // this thread's slot of facet 0; facets are 256 floats apart
+  bool keep;                 // coordinates are stored (nfct <= EU_MULTI_KEEP)
+};
+
 // the facet's environment with channel adaption; a real call (one body per
 // source channel count and degree, shared by all kernels of this file)
 template <int SN, int DEG>
-__device__ __noinline__ float4 eu_env_adapted(const eu_src_dev *s, int out_n, float rx, float ry,
-                                              float rz)
+__device__ __noinline__ float4 eu_env_adapted(const eu_src_dev *s, int out_n, bool hit, float sx,
+                                              float sy)
 {
   float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-  eu_environment_repix<SN, DEG>(*s, out_n, rx, ry, rz, t);
+  eu_environment_repix_at<SN, DEG>(*s, out_n, hit, sx, sy, t);
   return make_float4(t[0], t[1], t[2], t[3]);
 }
 
-// evaluate facet `want` (wave-divergent, -1: none) for this lane
+// facet f (wave-uniform) at this lane's source coordinate
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_env_facet(const eu_src_dev &s, bool hit, float sx, float sy,
+                                             float *out)
+{
+  if (s.nch == NCH) {
+    eu_environment_at<NCH, DEG>(s, hit, sx, sy, out);
+  } else {
+    // a facet with another channel count: repix_t inside its environment
+    // object (environment.h:1846-1900); f is wave-uniform, so is this switch
+    float4 t;
+    switch (s.nch) {
+      case 1: t = eu_env_adapted<1, DEG>(&s, NCH, hit, sx, sy); break;
+      case 2: t = eu_env_adapted<2, DEG>(&s, NCH, hit, sx, sy); break;
+      case 3: t = eu_env_adapted<3, DEG>(&s, NCH, hit, sx, sy); break;
+      default: t = eu_env_adapted<4, DEG>(&s, NCH, hit, sx, sy); break;
+    }
+    const float tt[4] = { t.x, t.y, t.z, t.w };
+#pragma unroll
+    for (int c = 0; c < NCH; c++) out[c] = tt[c];
+  }
+}
+
+// evaluate facet `want` (wave-divergent, -1: none) for this lane; hitm: the
+// facets this lane's ray hits (bit per facet)
 template <int NCH, int DEG>
 __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want, const eu_pix &px,
-                                              bool tap, float cx, float cy, float *out)
+                                              bool tap, float cx, float cy, const eu_slots &sl,
+                                              unsigned long long hitm, float *out)
 {
 #pragma unroll
   for (int c = 0; c < NCH; c++) out[c] = 0.0f;
@@ -90,25 +126,19 @@ __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want
     int first = __ffsll((long long)m) - 1;
     int f = __builtin_amdgcn_readlane(pending, first);
     if (pending == f) {
-      float rx, ry, rz;
-      eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
       const eu_src_dev &s = p.srcs[f];
-      if (s.nch == NCH) {
-        eu_environment<NCH, DEG>(s, rx, ry, rz, out);
+      float sx, sy;
+      bool hit;
+      if (sl.keep && !s.mask_all) {
+        sx = sl.sx[f * 256]; sy = sl.sy[f * 256];
+        hit = (hitm >> f) & 1ull;
       } else {
-        // a facet with another channel count: repix_t inside its environment
-        // object (environment.h:1846-1900); f is wave-uniform, so is this switch
-        float4 t;
-        switch (s.nch) {
-          case 1: t = eu_env_adapted<1, DEG>(&s, NCH, rx, ry, rz); break;
-          case 2: t = eu_env_adapted<2, DEG>(&s, NCH, rx, ry, rz); break;
-          case 3: t = eu_env_adapted<3, DEG>(&s, NCH, rx, ry, rz); break;
-          default: t = eu_env_adapted<4, DEG>(&s, NCH, rx, ry, rz); break;
-        }
-        const float tt[4] = { t.x, t.y, t.z, t.w };
-#pragma unroll
-        for (int c = 0; c < NCH; c++) out[c] = tt[c];
+        float rx, ry, rz;
+        int face;
+        eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+        hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
       }
+      eu_env_facet<NCH, DEG>(s, hit, sx, sy, out);
       pending = -1;
     }
   }
@@ -117,60 +147,92 @@ __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want
 // one synopsis evaluation for this lane
 template <int NCH, int DEG, bool PLUS>
 __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_pix &px,
-                                            bool live, bool tap, float cx, float cy, float *out)
+                                            bool live, bool tap, float cx, float cy,
+                                            const eu_slots &sl, float *out)
 {
   const int nf = p.nfct;
-  float zs[EU_MULTI_MAXF];
-  unsigned valid = 0;
-  // get_mask + z score of every facet
-#pragma unroll
-  for (int f = 0; f < EU_MULTI_MAXF; f++) {
-    zs[f] = 0.0f;
-    if (f < nf) {
-      float rx, ry, rz, sx, sy;
+  if constexpr (!PLUS) {
+    // _voronoi_syn: get_mask + z score of every facet; the largest z wins,
+    // strict '>' keeps the earlier facet. The champion's coordinate is kept.
+    int champ = -1;
+    float max_z = -3.402823466e+38f;          // numeric_limits<float>::lowest()
+    float csx = 0.0f, csy = 0.0f;
+    bool have = false;
+#pragma unroll 1
+    for (int f = 0; f < nf; f++) {
+      float rx, ry, rz, sx = 0.0f, sy = 0.0f;
       int face;
       eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
       const eu_src_dev &s = p.srcs[f];
-      bool hit = s.mask_all ? true : eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
-      if (hit && live) valid |= 1u << f;
-      zs[f] = rz * s.recip_step;
+      const bool masked = !s.mask_all;        // wave-uniform
+      const bool hit = masked ? eu_source_coordinate(s, rx, ry, rz, sx, sy, face) : true;
+      const float z = rz * s.recip_step;
+      if (hit && live && (f == 0 || z > max_z)) {
+        // f == 0: the reference seeds champion and max_z with facet 0 where it is valid
+        champ = f; max_z = z; csx = sx; csy = sy; have = masked;
+      }
     }
-  }
-  if constexpr (!PLUS) {
-    // _voronoi_syn: largest z wins, strict '>' keeps the earlier facet
-    int champ = -1;
-    float max_z = -3.402823466e+38f;          // numeric_limits<float>::lowest()
-    if (valid & 1u) { champ = 0; max_z = zs[0]; }
+    // evaluate the champion: waterfall over the facets the lanes chose
 #pragma unroll
-    for (int f = 1; f < EU_MULTI_MAXF; f++)
-      if (f < nf && ((valid >> f) & 1u) && zs[f] > max_z) { champ = f; max_z = zs[f]; }
-    eu_eval_facet<NCH, DEG>(p, champ, px, tap, cx, cy, out);
+    for (int c = 0; c < NCH; c++) out[c] = 0.0f;
+    int pending = champ;
+    while (true) {
+      unsigned long long m = __ballot(pending >= 0);
+      if (!m) break;
+      int first = __ffsll((long long)m) - 1;
+      int f = __builtin_amdgcn_readlane(pending, first);
+      if (pending == f) {
+        const eu_src_dev &s = p.srcs[f];
+        float sx = csx, sy = csy;
+        bool hit = true;
+        if (!have) {
+          float rx, ry, rz;
+          int face;
+          eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+          hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+        }
+        eu_env_facet<NCH, DEG>(s, hit, sx, sy, out);
+        pending = -1;
+      }
+    }
     return;
   } else {
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 4;
     const unsigned long long live_m = __ballot(live);
     const unsigned live_g = (unsigned)(live_m >> (16 * grp)) & 0xffffu;
+    unsigned long long valid = 0, hitm = 0;
     // next_best of this lane's vector: the last facet valid for any of its lanes
     int next_best = -1;
-#pragma unroll
-    for (int f = 0; f < EU_MULTI_MAXF; f++)
-      if (f < nf) {
-        unsigned long long b = __ballot((valid >> f) & 1u);
-        if ((unsigned)(b >> (16 * grp)) & 0xffffu) next_best = f;
-      }
-    // layer 0 of this lane
-    auto pick = [&](unsigned used) {
+#pragma unroll 1
+    for (int f = 0; f < nf; f++) {
+      float rx, ry, rz, sx = 0.0f, sy = 0.0f;
+      int face;
+      eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+      const eu_src_dev &s = p.srcs[f];
+      const bool hit = s.mask_all ? true : eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+      sl.z[f * 256] = rz * s.recip_step;
+      if (sl.keep) { sl.sx[f * 256] = sx; sl.sy[f * 256] = sy; }
+      if (hit) hitm |= 1ull << f;
+      const bool v = hit && live;
+      if (v) valid |= 1ull << f;
+      const unsigned long long bm = __ballot(v);
+      if ((unsigned)(bm >> (16 * grp)) & 0xffffu) next_best = f;
+    }
+    // the lane's nearest valid facet that is not used yet
+    auto pick = [&](unsigned long long used) {
       int best = -1;
       float bz = 0.0f;
-#pragma unroll
-      for (int f = 0; f < EU_MULTI_MAXF; f++)
-        if (f < nf && ((valid >> f) & 1u) && !((used >> f) & 1u)) {
-          if (best < 0 || zs[f] > bz) { best = f; bz = zs[f]; }
-        }
+      unsigned long long todo = valid & ~used;
+      while (todo) {
+        const int f = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const float z = sl.z[f * 256];
+        if (best < 0 || z > bz) { best = f; bz = z; }
+      }
       return best;
     };
-    const int top = pick(0u);
+    const int top = pick(0ull);
 #pragma unroll
     for (int c = 0; c < NCH; c++) out[c] = 0.0f;
     bool done = !live;
@@ -180,7 +242,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       unsigned long long tm = __ballot(live && top == next_best);
       bool all_top = !done && ((unsigned)(tm >> (16 * grp)) & 0xffffu) == live_g;
       float help[NCH];
-      eu_eval_facet<NCH, DEG>(p, all_top ? next_best : -1, px, tap, cx, cy, help);
+      eu_eval_facet<NCH, DEG>(p, all_top ? next_best : -1, px, tap, cx, cy, sl, hitm, help);
       unsigned long long om = __ballot(all_top && help[NCH - 1] >= 1.0f);
       bool opaque = all_top && ((unsigned)(om >> (16 * grp)) & 0xffffu) == live_g;
       if (opaque) {
@@ -190,15 +252,15 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       }
     }
     // general path: composite the lane's valid facets, nearest first
-    unsigned used = 0;
+    unsigned long long used = 0;
     int layer = 0;
     while (true) {
       int f = done ? -1 : pick(used);
       if (!__ballot(f >= 0)) break;
       float help[NCH];
-      eu_eval_facet<NCH, DEG>(p, f, px, tap, cx, cy, help);
+      eu_eval_facet<NCH, DEG>(p, f, px, tap, cx, cy, sl, hitm, help);
       if (f >= 0) {
-        used |= 1u << f;
+        used |= 1ull << f;
         if (layer == 0) {
 #pragma unroll
           for (int c = 0; c < NCH; c++) out[c] = help[c];
@@ -216,6 +278,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
 template <int NCH, int DEG, bool PLUS>
 __global__ __launch_bounds__(256) void eu_render_multi_kernel(const eu_multi_params p)
 {
+  extern __shared__ float eu_dyn_lds[];
   const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
   if (b < 0) return;
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
@@ -227,16 +290,21 @@ __global__ __launch_bounds__(256) void eu_render_multi_kernel(const eu_multi_par
   if (px.y >= p.row_end) return;              // wave-uniform
   const bool live = px.x < p.width;
   if (!live) px.x = p.width - 1;              // keeps table reads in range; no store
+  eu_slots sl;
+  sl.keep = p.nfct <= EU_MULTI_KEEP;
+  sl.z = eu_dyn_lds + threadIdx.x;
+  sl.sx = sl.z + p.nfct * 256;
+  sl.sy = sl.sx + p.nfct * 256;
   float out[NCH];
   if (!p.twine) {
-    eu_synopsis<NCH, DEG, PLUS>(p, px, live, false, 0.0f, 0.0f, out);
+    eu_synopsis<NCH, DEG, PLUS>(p, px, live, false, 0.0f, 0.0f, sl, out);
   } else {
 #pragma unroll
     for (int c = 0; c < NCH; c++) out[c] = 0.0f;
     for (int k = 0; k < p.ntaps; k++) {
       const float cx = p.taps[3 * k], cy = p.taps[3 * k + 1], cw = p.taps[3 * k + 2];
       float help[NCH];
-      eu_synopsis<NCH, DEG, PLUS>(p, px, live, true, cx, cy, help);
+      eu_synopsis<NCH, DEG, PLUS>(p, px, live, true, cx, cy, sl, help);
 #pragma unroll
       for (int c = 0; c < NCH; c++) out[c] = out[c] + cw * help[c];
     }
@@ -249,12 +317,15 @@ template <int NCH, bool PLUS>
 static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
 {
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), block(256);
+  // alpha compositing keeps z (and, for up to EU_MULTI_KEEP facets, the source
+  // coordinate) of every facet per thread in LDS
+  const size_t lds = PLUS ? (size_t)(p.nfct <= EU_MULTI_KEEP ? 3 : 1) * p.nfct * 256 * sizeof(float) : 0;
   switch (degree) {
-    case 0: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 0, PLUS>), grid, block, 0, st, p); break;
-    case 1: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 1, PLUS>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 2, PLUS>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 3, PLUS>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, PLUS>), grid, block, 0, st, p); break;
+    case 0: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 0, PLUS>), grid, block, lds, st, p); break;
+    case 1: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 1, PLUS>), grid, block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 2, PLUS>), grid, block, lds, st, p); break;
+    case 3: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 3, PLUS>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, PLUS>), grid, block, lds, st, p); break;
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

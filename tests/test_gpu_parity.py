@@ -404,3 +404,20 @@ def test_band_parts_assemble_the_frame(latlon, world, band):
     assert_bits(part, whole, "row ranges of a band part")
     with pytest.raises(ea.EuError):
         ea.render(a, g, 3, band=(6, world, 0))            # not a power of two
+
+
+@pytest.mark.parametrize("nch", [3, 4])
+def test_multi_facet_more_than_sixteen(nch):
+    """24 facets: the synopsis walks the facets with run-time loops (up to 64);
+    beyond 16 the coordinates are recomputed for the winners instead of kept"""
+    os_, gs = [], []
+    for k in range(4):
+        o6, g6 = facet_set(euo.RECTILINEAR, 48, 48, 70.0 + 5 * k, nch, 1, seed=40 + k)
+        os_ += o6
+        gs += g6
+    a = ea.arguments(ea.SPHERICAL, 160, 80, 360.0, yaw=11, pitch=3, spline_degree=1)
+    assert_bits(ea.render(a, gs, nch), jobs.oracle_render(a, os_), f"24 facets nch {nch}")
+    a = ea.arguments(ea.SPHERICAL, 96, 48, 360.0, spline_degree=1, twine=2)
+    assert_bits(ea.render(a, gs[:17], nch), jobs.oracle_render(a, os_[:17]), f"17 facets twined nch {nch}")
+    with pytest.raises(ea.EuError):
+        ea.render(a, gs * 3, nch)                      # 72 > 64
