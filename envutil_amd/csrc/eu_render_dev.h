@@ -7,6 +7,7 @@
 #include <climits>
 #include "eu_device.h"
 #include "eu_math.h"
+#include "eu_math2.h"
 
 #define EU_TILE_W 64
 #define EU_TILE_H 4
@@ -283,8 +284,10 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
   switch (s.prj) {
     case EU_SPHERICAL: {       // ray_to_ll_t, geometry.h:278-301
       float q = sqrtf(rx * rx + rz * rz);
-      c1 = eu_atan2f(ry, q);
-      c0 = eu_atan2f(rx, rz);
+      // the two atan2f as one packed evaluation (same bits as eu_atan2f, eu_math2.h)
+      const eu_f2 a = eu_atan2f_2((eu_f2){ ry, rx }, (eu_f2){ q, rz });
+      c1 = a.x;
+      c0 = a.y;
       break;
     }
     case EU_CYLINDRICAL: {     // ray_to_cyl_t, geometry.h:389-410
@@ -307,8 +310,9 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
     }
     default: {                 // ray_to_fish_t, geometry.h:513-531
       float q = sqrtf(rx * rx + ry * ry);
-      float r = (float)1.57079632679489661923 - eu_atan2f(rz, q);
-      float phi = eu_atan2f(ry, rx);
+      const eu_f2 a = eu_atan2f_2((eu_f2){ rz, ry }, (eu_f2){ q, rx });
+      float r = (float)1.57079632679489661923 - a.x;
+      float phi = a.y;
       c0 = r * eu_cosf(phi);
       c1 = r * eu_sinf(phi);
       break;
