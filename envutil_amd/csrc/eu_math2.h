@@ -267,4 +267,38 @@ EU_D2 eu_f2 eu_atan2f_2_tab(eu_f2 y, eu_f2 x, const float *tab, int x_positive)
   return r;
 }
 
+#if defined(__HIPCC__)
+// n / d: range-checked FMA division (eu_div2_safe), hipcc's correctly rounded
+// `/` for the lanes outside the range - the same bits either way
+__device__ __forceinline__ eu_f2 eu_div2_guarded(eu_f2 n, eu_f2 d)
+{
+  const eu_u2 in = eu_bits2(n) & 0x7fffffffu, id = eu_bits2(d) & 0x7fffffffu;
+  // d in [2^-40, 2^40]; n zero or in [2^-80, 2^40]
+  const eu_i2 okd = (id - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 okn = (in == 0u) | ((in - 0x17800000u) <= (0x53800000u - 0x17800000u));
+  const eu_i2 ok = okd & okn;
+  const eu_f2 one = { 1.0f, 1.0f };
+  eu_f2 q = eu_div2_safe(eu_sel2(ok, n, one), eu_sel2(ok, d, one));
+  if (__builtin_expect(!(ok.x & ok.y), 0)) {
+    if (!ok.x) q.x = n.x / d.x;
+    if (!ok.y) q.y = n.y / d.y;
+  }
+  return q;
+}
+
+// sqrt(x): eu_sqrt2_safe for x in [2^-40, 2^40], sqrtf for the other lanes
+__device__ __forceinline__ eu_f2 eu_sqrt2_guarded(eu_f2 x)
+{
+  const eu_u2 ix = eu_bits2(x);
+  const eu_i2 ok = (ix - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_f2 one = { 1.0f, 1.0f };
+  eu_f2 r = eu_sqrt2_safe(eu_sel2(ok, x, one));
+  if (__builtin_expect(!(ok.x & ok.y), 0)) {
+    if (!ok.x) r.x = sqrtf(x.x);
+    if (!ok.y) r.y = sqrtf(x.y);
+  }
+  return r;
+}
+#endif
+
 #endif

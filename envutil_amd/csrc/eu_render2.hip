@@ -189,24 +189,6 @@ __device__ __forceinline__ eu_ray2 eu_rays2(int form, int norm_mode, eu_cptr row
 // both lanes: ray -> source pixel coordinate (+ hit mask)
 // ---------------------------------------------------------------------------
 
-// x / y for lanes where y dominates: |x| <= |y|. Range-checked FMA division,
-// true division for the rest.
-__device__ __forceinline__ eu_f2 eu_div2_guarded(eu_f2 n, eu_f2 d)
-{
-  const eu_u2 in = eu_bits2(n) & 0x7fffffffu, id = eu_bits2(d) & 0x7fffffffu;
-  // d in [2^-40, 2^40]; n zero or >= 2^-80
-  const eu_i2 okd = (id - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
-  const eu_i2 okn = (in == 0u) | ((in - 0x17800000u) <= (0x53800000u - 0x17800000u));
-  const eu_i2 ok = okd & okn;
-  const eu_f2 one = { 1.0f, 1.0f };
-  eu_f2 q = eu_div2_safe(eu_sel2(ok, n, one), eu_sel2(ok, d, one));
-  if (__builtin_expect(!(ok.x & ok.y), 0)) {
-    if (!ok.x) q.x = n.x / d.x;
-    if (!ok.y) q.y = n.y / d.y;
-  }
-  return q;
-}
-
 template <int PRJ>
 __device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r, eu_f2 &sx,
                                            eu_f2 &sy, const float *atab)
@@ -242,16 +224,7 @@ __device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r
   } else {
     // ray_to_ll_t (geometry.h:278-301): s = sqrt(r*r + f*f); lat = atan2(d, s); lon = atan2(r, f)
     eu_f2 q2 = r.x * r.x + r.z * r.z;
-    eu_f2 qs;
-    {
-      const eu_u2 iq = eu_bits2(q2);
-      const eu_i2 ok = (iq - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
-      qs = eu_sqrt2_safe(q2);      // out-of-range lanes are replaced below
-      if (__builtin_expect(!(ok.x & ok.y), 0)) {
-        if (!ok.x) qs.x = sqrtf(q2.x);
-        if (!ok.y) qs.y = sqrtf(q2.y);
-      }
-    }
+    const eu_f2 qs = eu_sqrt2_guarded(q2);
     // s == 0 (ray along the vertical axis) fails the range check and takes the scalar path
     eu_f2 lat = eu_atan2f_2_tab(r.y, qs, atab, 1);
     eu_f2 lon = eu_atan2f_2_tab(r.x, r.z, atab, 0);
