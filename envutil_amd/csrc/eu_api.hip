@@ -160,6 +160,31 @@ void fill_src_dev(eu_source *s)
     d.lens_h = (float)f.h; d.lens_v = (float)f.v;
     d.shear_g = f.shear_g; d.shear_t = f.shear_t;
   }
+  d.rej_cos = -2.0f;
+  if (f.projection == EU_RECTILINEAR) {
+    d.rej_cos = 0.0f;                      // the mask includes rz > 0 (environment.h:1135-1137)
+  } else if (f.projection == EU_FISHEYE && !d.has_shear) {
+    // radius after the lens polynomial: |c'| >= r * |sum(r / s)| - |shift|; outside the
+    // window for sure when its larger component (>= |c'| / sqrt 2) exceeds every edge
+    const double W = 1.001 * std::max(std::max(std::fabs(we[0]), std::fabs(we[1])),
+                                      std::max(std::fabs(we[2]), std::fabs(we[3])));
+    const double shift = d.has_shift ? std::hypot((double)d.lens_h, (double)d.lens_v) : 0.0;
+    auto outside = [&](double r) {
+      double sum = 1.0;
+      if (d.has_lcp) {
+        const double x = r / d.lens_s;
+        sum = d.lens_d + d.lens_c * x + d.lens_b * x * x + d.lens_a * x * x * x;
+      }
+      return (r * std::fabs(sum) - shift) / std::sqrt(2.0) > W;
+    };
+    // the smallest angle from which EVERY larger angle is outside
+    double r0 = -1.0;
+    for (double r = M_PI; r >= 0.0; r -= 1e-4) {
+      if (!outside(r)) break;
+      r0 = r;
+    }
+    if (r0 >= 0.0) d.rej_cos = (float)(std::cos(r0) - 1e-4);
+  }
   d.tex_x0 = te[0]; d.tex_y0 = te[2];
   d.ext_w = (float)(te[1] - te[0]); d.ext_h = (float)(te[3] - te[2]);
   d.total_w = (float)f.width; d.total_h = (float)f.height;

@@ -45,6 +45,12 @@ struct eu_src_dev {
   double shear_g, shear_t;
   float recip_step;          // float(1.0 / facet.step): z-score weight of the synopsis
   int mask_all;              // get_mask is constant true (cubemaps, fisheye with hfov >= 2 pi)
+  // conservative early miss for the multi-facet mask pass: a ray with
+  // rz < rej_cos * |ray| cannot land in the facet's window (fisheye: the angle
+  // from the facet's axis maps, through the lens polynomial, to a radius whose
+  // larger component already exceeds the window by 0.1 %; rectilinear: rays from
+  // behind). -2: no such bound. Only whole wavefronts skip the exact test.
+  float rej_cos;
   // cubemap_view_t (environment.h:1425-1460)
   float refc_md, model_to_px;
   int section_px;

@@ -165,7 +165,13 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
       const eu_src_dev &s = p.srcs[f];
       const bool masked = !s.mask_all;        // wave-uniform
-      const bool hit = masked ? eu_source_coordinate(s, rx, ry, rz, sx, sy, face) : true;
+      bool hit = true;
+      if (masked) {
+        // whole wavefront provably outside the facet's window: skip the exact test
+        const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+        hit = false;
+        if (__ballot(maybe)) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+      }
       const float z = rz * s.recip_step;
       if (hit && live && (f == 0 || z > max_z)) {
         // f == 0: the reference seeds champion and max_z with facet 0 where it is valid
@@ -210,7 +216,13 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       int face;
       eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
       const eu_src_dev &s = p.srcs[f];
-      const bool hit = s.mask_all ? true : eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+      bool hit = true;
+      if (!s.mask_all) {
+        // whole wavefront provably outside the facet's window: skip the exact test
+        const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+        hit = false;
+        if (__ballot(maybe)) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+      }
       sl.z[f * 256] = rz * s.recip_step;
       if (sl.keep) { sl.sx[f * 256] = sx; sl.sy[f * 256] = sy; }
       if (hit) hitm |= 1ull << f;
