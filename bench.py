@@ -286,15 +286,23 @@ def main():
     }
 
     # ---- CPU baseline: the oracle (a port) on a band of rows, rank 0, N=1 ----
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and nsrcs == 1:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import euo
         import jobs
-        cont = src.download()
-        g, _ = src.info()
-        osrc = jobs.oracle_source_from_container(
-            sprj, sw, sh, shfov, cont, g, degree, nch,
-            ea.cubemap_metrics(sw) if sprj in (ea.CUBEMAP, ea.BIATAN6) else None)
+        osrc = []
+        for k, sk in enumerate(sources):
+            cont = sk.download()
+            g, _ = sk.info()
+            extra = {}
+            if a.workload == "config5":
+                extra = dict(yaw=views[k][0], pitch=views[k][1], roll=views[k][2],
+                             lens=dict(a=0.01, b=-0.03, c=0.02))
+            osrc.append(jobs.oracle_source_from_container(
+                sprj, sw, sh, shfov, cont, g, degree, nch,
+                ea.cubemap_metrics(sw) if sprj in (ea.CUBEMAP, ea.BIATAN6) else None, **extra))
+        if nsrcs == 1:
+            osrc = osrc[0]
         cores = os.cpu_count() or 1
         try:
             cores = len(os.sched_getaffinity(0))
@@ -316,7 +324,7 @@ def main():
         dt = time.perf_counter() - t
         # the same rows from the GPU: the baseline run doubles as a full-size
         # parity spot check
-        chk = ea.render(args, src, nch, b0, b0 + rows)
+        chk = ea.render(args, sources, nch, b0, b0 + rows)
         same = bool((chk.view(np.uint32) == ref.view(np.uint32)).all())
         result["cpu_baseline"] = {
             "value": round(rows * tw / dt / 1e6, 2), "unit": "Mpix/s", "cores": cores,

@@ -98,7 +98,7 @@ class OracleSource:
 
 
 def oracle_source_from_container(prj, width, height, hfov_deg, container, geom, degree, nch,
-                                 cubemap_metrics=None):
+                                 cubemap_metrics=None, yaw=0.0, pitch=0.0, roll=0.0, lens=None):
     """an OracleSource over a finished (braced, prefiltered) coefficient array, e.g. the
     one a GPU source downloads: the oracle then evaluates exactly what the kernels read.
     geom: envutil_amd Container (shape/left/right/core); cubemap_metrics: dict of
@@ -110,7 +110,12 @@ def oracle_source_from_container(prj, width, height, hfov_deg, container, geom, 
     s.width, s.height = width, height
     s.window_width, s.window_height = width, height
     s.brighten = 1.0
+    s.yaw, s.pitch, s.roll = (math.radians(v) for v in (yaw, pitch, roll))
     s.step = euo.lib().euo_get_step(prj, width, height, s.hfov)
+    if lens:
+        for k, v in lens.items():
+            setattr(s, {"g": "shear_g", "t": "shear_t"}.get(k, k), v)
+        s.has_lcp = int(any(lens.get(k, 0.0) != 0.0 for k in "abc"))
     sp = euo.Spline()
     sp.data = container.ctypes.data_as(C.POINTER(C.c_float))
     sp.shape[0], sp.shape[1] = geom.shape[0], geom.shape[1]
