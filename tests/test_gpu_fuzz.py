@@ -1,0 +1,88 @@
+"""Randomised differential test: jobs drawn from the whole parameter space
+(source and target projections, fields of view, orientations, spline degrees,
+channel counts, twining, crop windows, band tilings, tethered output) rendered
+by the HIP library and by the oracle; every float / word must be identical."""
+import numpy as np
+import pytest
+
+import envutil_amd as ea
+import euo
+import jobs
+
+pytestmark = pytest.mark.gpu
+
+SRC_PRJ = [euo.SPHERICAL, euo.CYLINDRICAL, euo.RECTILINEAR, euo.STEREOGRAPHIC, euo.FISHEYE,
+           euo.CUBEMAP, euo.BIATAN6]
+TRG_PRJ = [ea.SPHERICAL, ea.CYLINDRICAL, ea.RECTILINEAR, ea.STEREOGRAPHIC, ea.FISHEYE, ea.CUBEMAP,
+           ea.BIATAN6]
+
+
+def draw_job(rng):
+    sprj = SRC_PRJ[rng.integers(len(SRC_PRJ))]
+    nch = int(rng.integers(1, 5))
+    degree = int(rng.choice([0, 1, 1, 2, 3, 3, 4, 5]))
+    if sprj in (euo.CUBEMAP, euo.BIATAN6):
+        face = int(rng.integers(16, 48))
+        sw, sh, shfov = face, 6 * face, 90.0
+    else:
+        sw, sh = int(rng.integers(24, 160)), int(rng.integers(24, 120))
+        full = sprj in (euo.SPHERICAL, euo.CYLINDRICAL) and rng.random() < 0.5
+        if sprj == euo.SPHERICAL and full:
+            sh = max(12, sw // 2)
+            sw = 2 * sh
+        shfov = 360.0 if full else float(rng.uniform(40.0, {euo.RECTILINEAR: 130.0, euo.STEREOGRAPHIC: 250.0,
+                                                            euo.FISHEYE: 300.0}.get(sprj, 300.0)))
+    tprj = TRG_PRJ[rng.integers(len(TRG_PRJ))]
+    if tprj in (ea.CUBEMAP, ea.BIATAN6):
+        tw = int(rng.integers(8, 40))
+        th, thfov = 6 * tw, 90.0
+    else:
+        tw, th = int(rng.integers(1, 200)), int(rng.integers(1, 90))
+        thfov = float(rng.uniform(30.0, {ea.RECTILINEAR: 140.0, ea.STEREOGRAPHIC: 300.0}.get(tprj, 360.0)))
+    kw = dict(yaw=float(rng.uniform(-180, 180)), pitch=float(rng.uniform(-90, 90)),
+              roll=float(rng.uniform(-180, 180)), spline_degree=degree,
+              twine=int(rng.choice([0, 0, 2, 3])))
+    if rng.random() < 0.25 and tw >= 4 and th >= 4:
+        x0, y0 = int(rng.integers(0, tw // 2)), int(rng.integers(0, th // 2))
+        kw["crop"] = (x0, int(rng.integers(x0 + 1, tw + 1)), y0, int(rng.integers(y0 + 1, th + 1)))
+    if rng.random() < 0.2:
+        kw["tethered"] = True
+    src_kw = dict(yaw=float(rng.uniform(-180, 180)), pitch=float(rng.uniform(-90, 90)),
+                  roll=float(rng.uniform(-30, 30)), brighten=float(rng.choice([1.0, 1.0, 0.8, 1.3])))
+    if sprj in (euo.RECTILINEAR, euo.FISHEYE, euo.STEREOGRAPHIC, euo.CYLINDRICAL) and rng.random() < 0.3:
+        src_kw["lens"] = dict(a=float(rng.uniform(-0.02, 0.02)), b=float(rng.uniform(-0.04, 0.04)),
+                              c=float(rng.uniform(-0.03, 0.03)), h=float(rng.choice([0.0, 0.01])),
+                              v=float(rng.choice([0.0, -0.02])))
+    out_n = nch if rng.random() < 0.8 else int(rng.integers(1, 5))
+    band = None
+    if rng.random() < 0.25:
+        cnt = int(rng.integers(2, 5))
+        band = (int(rng.choice([4, 8, 16])), cnt, int(rng.integers(0, cnt)))
+    return sprj, sw, sh, shfov, nch, degree, tprj, tw, th, thfov, kw, src_kw, out_n, band
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_jobs_bit_identical(seed):
+    rng = np.random.default_rng(1000 + seed)
+    for k in range(6):
+        sprj, sw, sh, shfov, nch, degree, tprj, tw, th, thfov, kw, src_kw, out_n, band = draw_job(rng)
+        img = jobs.synth_image(sw, sh, nch, seed=seed * 100 + k)
+        o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree, **src_kw)
+        g = ea.Source.adopt(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch, yaw=src_kw["yaw"],
+                                          pitch=src_kw["pitch"], roll=src_kw["roll"],
+                                          brighten=src_kw["brighten"], lens=src_kw.get("lens")),
+                            o.container, degree, o.bc[0], o.bc[1])
+        a = ea.arguments(tprj, tw, th, thfov, **kw)
+        what = f"seed {seed} job {k}: src {sprj} {sw}x{sh} fov {shfov:.1f} nch {nch} deg {degree} -> " \
+               f"trg {tprj} {tw}x{th} fov {thfov:.1f} {kw} out {out_n} band {band} lens {src_kw.get('lens')}"
+        ref = jobs.oracle_render(a, o, nch=out_n)
+        if band is None:
+            got = ea.render(a, g, out_n)
+        else:
+            rows = ea.band_frame_rows(a.out_height, *band)
+            got = ea.render(a, g, out_n, band=band)
+            ref = ref[rows]
+        assert got.shape == ref.shape, what
+        same = got.view(np.uint32) == ref.view(np.uint32)
+        assert same.all(), f"{what}: {int((~same).sum())} of {same.size} words differ"
+        g.release()
