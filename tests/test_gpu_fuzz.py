@@ -86,3 +86,46 @@ def test_random_jobs_bit_identical(seed):
         same = got.view(np.uint32) == ref.view(np.uint32)
         assert same.all(), f"{what}: {int((~same).sum())} of {same.size} words differ"
         g.release()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_multi_facet_jobs_bit_identical(seed):
+    """2-9 facets of mixed projections, channel counts, orientations, lens
+    parameters; voronoi_syn / voronoi_syn_plus by the job's channel count"""
+    rng = np.random.default_rng(5000 + seed)
+    for k in range(2):
+        nf = int(rng.integers(2, 10))
+        degree = int(rng.choice([0, 1, 1, 2, 3, 4]))
+        out_n = int(rng.integers(1, 5))
+        os_, gs = [], []
+        for f in range(nf):
+            sprj, sw, sh, shfov, nch, _, _, _, _, _, _, src_kw, _, _ = draw_job(rng)
+            if rng.random() < 0.7:
+                nch = out_n                         # mostly uniform channel counts, sometimes mixed
+            img = jobs.synth_image(sw, sh, nch, seed=seed * 1000 + k * 50 + f)
+            if nch in (2, 4):
+                yy, xx = np.mgrid[0:sh, 0:sw]
+                r = np.hypot((xx - sw / 2) / (sw / 2), (yy - sh / 2) / (sh / 2))
+                img[:, :, nch - 1] = np.clip(1.5 - 1.3 * r, 0.0, 1.0)
+            o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree, **src_kw)
+            gs.append(ea.Source.adopt(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch, yaw=src_kw["yaw"],
+                                                    pitch=src_kw["pitch"], roll=src_kw["roll"],
+                                                    brighten=src_kw["brighten"], lens=src_kw.get("lens")),
+                                      o.container, degree, o.bc[0], o.bc[1]))
+            os_.append(o)
+        tprj = TRG_PRJ[rng.integers(len(TRG_PRJ))]
+        if tprj in (ea.CUBEMAP, ea.BIATAN6):
+            tw = int(rng.integers(8, 32))
+            th, thfov = 6 * tw, 90.0
+        else:
+            tw, th = int(rng.integers(1, 150)), int(rng.integers(1, 70))
+            thfov = float(rng.uniform(30.0, {ea.RECTILINEAR: 140.0, ea.STEREOGRAPHIC: 300.0}.get(tprj, 360.0)))
+        a = ea.arguments(tprj, tw, th, thfov, yaw=float(rng.uniform(-180, 180)),
+                         pitch=float(rng.uniform(-90, 90)), roll=float(rng.uniform(-180, 180)),
+                         spline_degree=degree, twine=int(rng.choice([0, 0, 2])))
+        got, ref = ea.render(a, gs, out_n), jobs.oracle_render(a, os_, nch=out_n)
+        same = got.view(np.uint32) == ref.view(np.uint32)
+        assert same.all(), f"seed {seed} job {k}: {nf} facets deg {degree} out {out_n} trg {tprj} {tw}x{th}: " \
+                           f"{int((~same).sum())} of {same.size} words differ"
+        for g in gs:
+            g.release()
