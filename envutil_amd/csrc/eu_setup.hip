@@ -151,6 +151,55 @@ __device__ float iacc(const iir_dev &f, const L &c, int M, int k)
   }
 }
 
+// The recursions are sequential by definition (and stay so: same operations in
+// the same order as recursive.h), but their LOADS are not: a line is walked in
+// blocks of EU_IIR_BLOCK samples that are read into registers first, so that a
+// thread has that many loads in flight instead of one per dependent step.
+#define EU_IIR_BLOCK 16
+
+// forward: X = gain * x[n] + p * X (gain == 1 and the product skipped for k > 0)
+template <bool GAIN, class L>
+__device__ __forceinline__ float causal_pass(const L &x, int M, float g, float p, float X)
+{
+  int n = 1;
+  for (; n + EU_IIR_BLOCK <= M; n += EU_IIR_BLOCK) {
+    float v[EU_IIR_BLOCK];
+#pragma unroll
+    for (int i = 0; i < EU_IIR_BLOCK; i++) v[i] = x.get(n + i);
+#pragma unroll
+    for (int i = 0; i < EU_IIR_BLOCK; i++) {
+      if constexpr (GAIN) X = g * v[i] + p * X;
+      else X = v[i] + p * X;
+      v[i] = X;
+    }
+#pragma unroll
+    for (int i = 0; i < EU_IIR_BLOCK; i++) x.put(n + i, v[i]);
+  }
+  for (; n < M; n++) {
+    if constexpr (GAIN) X = g * x.get(n) + p * X;
+    else X = x.get(n) + p * X;
+    x.put(n, X);
+  }
+  return X;
+}
+
+// backward from M - 2: X = p * (X - x[n])
+template <class L>
+__device__ __forceinline__ void anticausal_pass(const L &x, int M, float p, float X)
+{
+  int n = M - 2;
+  for (; n - (EU_IIR_BLOCK - 1) >= 0; n -= EU_IIR_BLOCK) {
+    float v[EU_IIR_BLOCK];
+#pragma unroll
+    for (int i = 0; i < EU_IIR_BLOCK; i++) v[i] = x.get(n - i);
+#pragma unroll
+    for (int i = 0; i < EU_IIR_BLOCK; i++) { X = p * (X - v[i]); v[i] = X; }
+#pragma unroll
+    for (int i = 0; i < EU_IIR_BLOCK; i++) x.put(n - i, v[i]);
+  }
+  for (; n >= 0; n--) { X = p * (X - x.get(n)); x.put(n, X); }
+}
+
 // recursive.h:631-733, in place
 template <class L>
 __device__ void solve_line(const iir_dev &f, const L &x, int M)
@@ -159,18 +208,18 @@ __device__ void solve_line(const iir_dev &f, const L &x, int M)
   float p = f.pole[0], g = f.gain;
   float X = g * icc(f, x, M, 0);
   x.put(0, X);
-  for (int n = 1; n < M; n++) { X = g * x.get(n) + p * X; x.put(n, X); }
+  causal_pass<true>(x, M, g, p, X);
   X = iacc(f, x, M, 0);
   x.put(M - 1, X);
-  for (int n = M - 2; n >= 0; n--) { X = p * (X - x.get(n)); x.put(n, X); }
+  anticausal_pass(x, M, p, X);
   for (int k = 1; k < f.npoles; k++) {
     p = f.pole[k];
     X = icc(f, x, M, k);
     x.put(0, X);
-    for (int n = 1; n < M; n++) { X = x.get(n) + p * X; x.put(n, X); }
+    causal_pass<false>(x, M, 1.0f, p, X);
     X = iacc(f, x, M, k);
     x.put(M - 1, X);
-    for (int n = M - 2; n >= 0; n--) { X = p * (X - x.get(n)); x.put(n, X); }
+    anticausal_pass(x, M, p, X);
   }
 }
 
