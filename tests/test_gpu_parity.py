@@ -421,3 +421,30 @@ def test_multi_facet_more_than_sixteen(nch):
     assert_bits(ea.render(a, gs[:17], nch), jobs.oracle_render(a, os_[:17]), f"17 facets twined nch {nch}")
     with pytest.raises(ea.EuError):
         ea.render(a, gs * 3, nch)                      # 72 > 64
+
+
+# ---- targets whose rows share stepper constants (cube faces, unpitched targets) -----
+
+@pytest.mark.parametrize("ypr", [(0, 0, 0), (37.5, 0, 0), (-90, 0, 0), (0, 0.5, 0)])
+@pytest.mark.parametrize("degree", [1, 2, 3])
+def test_column_invariant_longitude_paths(latlon, ypr, degree):
+    """unrotated and yaw-only targets (the source column then depends on the target
+    column only - the common lat/lon -> cubemap conversion) next to a slightly
+    pitched one, all packed-kernel degrees and channel counts, cropped and banded"""
+    for nch in (1, 3, 4):
+        o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[nch], degree)
+        for tprj, tw, th, thfov in [(ea.CUBEMAP, 70, 420, 90.0), (ea.RECTILINEAR, 300, 200, 100.0),
+                                    (ea.CYLINDRICAL, 333, 130, 360.0), (ea.BIATAN6, 66, 396, 90.0),
+                                    (ea.SPHERICAL, 256, 128, 360.0)]:
+            a = ea.arguments(tprj, tw, th, thfov, yaw=ypr[0], pitch=ypr[1], roll=ypr[2], spline_degree=degree)
+            assert_bits(ea.render(a, g), jobs.oracle_render(a, o), f"ypr {ypr} deg {degree} nch {nch} trg {tprj}")
+    # cropped and band-tiled
+    o, g = make_pair(euo.SPHERICAL, SRC_W, SRC_H, 360.0, latlon[3], degree)
+    a = ea.arguments(ea.CUBEMAP, 70, 420, 90.0, yaw=ypr[0], pitch=ypr[1], roll=ypr[2], spline_degree=degree,
+                     crop=(3, 69, 50, 400))
+    assert_bits(ea.render(a, g), jobs.oracle_render(a, o), "unpitched, cropped")
+    a = ea.arguments(ea.CUBEMAP, 70, 420, 90.0, yaw=ypr[0], pitch=ypr[1], roll=ypr[2], spline_degree=degree)
+    ref = jobs.oracle_render(a, o)
+    for part in range(3):
+        rows = ea.band_frame_rows(a.height, 8, 3, part)
+        assert_bits(ea.render(a, g, 3, band=(8, 3, part)), ref[rows], "unpitched, bands")
