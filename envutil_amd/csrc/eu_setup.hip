@@ -375,15 +375,12 @@ __device__ __forceinline__ float mirror_gate(float c, float lower, float upper)
 }
 
 // fill_frame_t::eval, cubemap.h:724-809, for every frame pixel of one face
-__global__ void fill_frame_kernel(float *ir, int nch, int face, long long F, long long S,
-                                  long long lf, long long rf, double refc_md,
-                                  double model_to_px)
+// fill_frame_t (cubemap.h:700-810) for frame pixel (x, y) of `face`'s section:
+// the ray through the pixel, the cube face it hits, the pick-up coordinate in the
+// IR, the bilinear sample from the IR as it stands; out[nch]
+__device__ void fill_px(const float *ir, int nch, int face, long long x, long long y, long long S,
+                        double refc_md, double model_to_px, float *out)
 {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= S * S) return;
-  long long x = t % S, y = t / S;
-  bool frame = y < lf || y >= S - rf || x < lf || x >= lf + F;
-  if (!frame) return;
   int ishift = (int)S - 1, ithird = (int)(model_to_px * 2);
   int ix = (int)(2 * x) - ishift, iy = (int)(2 * y) - ishift;
   float c3[3];
@@ -417,7 +414,6 @@ __global__ void fill_frame_kernel(float *ir, int nch, int face, long long F, lon
   float tx = gx - fx, ty = gy - fy;
   const float *p = ir + ((long long)(int)fy * S + (long long)(int)fx) * nch;
   float wl0 = 1.0f - tx, wr0 = tx, wl1 = 1.0f - ty, wr1 = ty;
-  float *dst = ir + (((long long)face * S + y) * S + x) * nch;
   for (int c = 0; c < nch; c++) {
     float sum = p[c] * wl0;
     sum = sum + p[nch + c] * wr0;
@@ -425,7 +421,75 @@ __global__ void fill_frame_kernel(float *ir, int nch, int face, long long F, lon
     float sub = p[S * nch + c] * wl0;
     sub = sub + p[S * nch + nch + c] * wr0;
     sum = sum + sub * wr1;
-    dst[c] = sum;
+    out[c] = sum;
+  }
+}
+
+// One of the four stripes of a section's frame, in the order fill_support works
+// through them (cubemap.h:870-908): 0 above, 1 below, 2 left, 3 right of the cube
+// face. The order is part of the result when the frame is one pixel wider on the
+// right than on the left (odd face sizes): the frame pixels in the row below / the
+// column right of the face then tie in the dominant-axis test and map onto their
+// OWN face's edge, i.e. they read frame pixels of this section - among them their
+// left / upper neighbour. `tie` excludes that row (stripe 1) / column (stripe 3)
+// here; fill_tie_kernel does them in the reference's single-thread order.
+__global__ void fill_frame_kernel(float *ir, int nch, int face, int stripe, long long F, long long S,
+                                  long long lf, long long rf, double refc_md,
+                                  double model_to_px, int tie)
+{
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= S * S) return;
+  long long x = t % S, y = t / S;
+  bool mine;
+  switch (stripe) {
+    case 0: mine = y < lf; break;
+    case 1: mine = y >= S - rf && !(tie && y == lf + F); break;
+    case 2: mine = x < lf && y >= lf && y < S - rf; break;
+    default: mine = x >= lf + F && y >= lf && y < S - rf && !(tie && x == lf + F); break;
+  }
+  if (!mine) return;
+  float v[4];
+  fill_px(ir, nch, face, x, y, S, refc_md, model_to_px, v);
+  float *dst = ir + (((long long)face * S + y) * S + x) * nch;
+  for (int c = 0; c < nch; c++) dst[c] = v[c];
+}
+
+// The tie row / column, ONE wavefront, in the order of zimt::process with one
+// worker thread (wielding.h:337-463): stripe 1: the row y = lf + F in vectors of
+// 16 pixels from x = 0, every vector evaluated from the array as it stands and
+// then stored; stripe 3: the column x = lf + F row by row (it is the first lane
+// of each row's vector, which reads the pixel above it).
+__global__ void fill_tie_kernel(float *ir, int nch, int face, int stripe, long long F, long long S,
+                                long long lf, long long rf, double refc_md, double model_to_px)
+{
+  const int lane = threadIdx.x;
+  float *sec = ir + (long long)face * S * S * nch;
+  if (stripe == 1) {
+    const long long y = lf + F;
+    for (long long x0 = 0; x0 < S; x0 += 16) {
+      const long long x = x0 + lane;
+      const bool on = lane < 16 && x < S;
+      float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+      if (on) fill_px(ir, nch, face, x, y, S, refc_md, model_to_px, v);
+      // every lane's reads are done before any lane stores
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (on) for (int c = 0; c < nch; c++) sec[(y * S + x) * nch + c] = v[c];
+      __threadfence();
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    const long long x = lf + F;
+    for (long long y = lf; y < S - rf; y++) {
+      float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+      if (lane == 0) {
+        fill_px(ir, nch, face, x, y, S, refc_md, model_to_px, v);
+        for (int c = 0; c < nch; c++) sec[(y * S + x) * nch + c] = v[c];
+      }
+      __threadfence();
+      __builtin_amdgcn_s_waitcnt(0);
+    }
   }
 }
 
@@ -491,10 +555,20 @@ extern "C" int eu_launch_cubemap_build(const float *faces, float *ir, int nch, l
     hipLaunchKernelGGL(mirror_around_kernel, dim3(blocks_for(6LL * 4 * (F + 2) * nch, 256)),
                        dim3(256), 0, st, ir, nch, (long long)F, (long long)S, (long long)lf,
                        (long long)rf);
+    // the row below / column right of the face ties with the face's own edge when
+    // 2 * (lf + F) - (S - 1) equals int(2 * model_to_px), i.e. rf == lf + 1
+    const int tie = rf > 0 && 2 * (lf + F) - (S - 1) == (long)(int)(model_to_px * 2);
     for (int face = 0; face < 6; face++)
-      hipLaunchKernelGGL(fill_frame_kernel, dim3(blocks_for((long long)S * S, 256)), dim3(256), 0,
-                         st, ir, nch, face, (long long)F, (long long)S, (long long)lf,
-                         (long long)rf, refc_md, model_to_px);
+      for (int stripe = 0; stripe < 4; stripe++) {
+        if ((stripe == 0 || stripe == 2) ? lf <= 0 : rf <= 0) continue;
+        hipLaunchKernelGGL(fill_frame_kernel, dim3(blocks_for((long long)S * S, 256)), dim3(256), 0,
+                           st, ir, nch, face, stripe, (long long)F, (long long)S, (long long)lf,
+                           (long long)rf, refc_md, model_to_px, tie);
+        if (tie && (stripe == 1 || stripe == 3))
+          hipLaunchKernelGGL(fill_tie_kernel, dim3(1), dim3(64), 0, st, ir, nch, face, stripe,
+                             (long long)F, (long long)S, (long long)lf, (long long)rf, refc_md,
+                             model_to_px);
+      }
   }
   if (prefilter_degree > 1) {
     // cubemap.h:921-946: per section, NATURAL x NATURAL, default tolerance

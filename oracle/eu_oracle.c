@@ -988,13 +988,27 @@ void euo_cubemap_build(const euo_metrics *m, const float *faces, int nch,
         { 0, lf, lf, S - rf },
         { lf + F, lf, S, S - rf } };
       int on[4] = { lf > 0, rf > 0, lf > 0, rf > 0 };
+      /* The order is part of the result. With an odd face size (right frame =
+       * left frame + 1) the frame pixels in the row / column next to the face tie
+       * in the dominant-axis test and map onto their OWN face's edge: they read
+       * frame pixels of this section, among them the one to their left / above.
+       * The restated order is the reference's with one worker thread: stripes in
+       * the order above, below, left, right; rows top to bottom; a row in vectors
+       * of 16 lanes from the window's first column, every vector evaluated from
+       * the array as it stands and then stored (zimt::process, wielding.h:337-463).
+       * (With several threads the reference races on exactly these pixels.) */
       for (int k = 0; k < 4; k++) {
         if (!on[k]) continue;
-#pragma omp parallel for schedule(static)
         for (long y = win[k][1]; y < win[k][3]; y++)
-          for (long x = win[k][0]; x < win[k][2]; x++)
-            fill_frame_px(m, &bil, f, (int)(2 * x - ishift), (int)(2 * y - ishift),
-                          ithird, sec + (y * S + x) * nch);
+          for (long x0 = win[k][0]; x0 < win[k][2]; x0 += EUO_LANES) {
+            float tmp[EUO_LANES][4];
+            long n = win[k][2] - x0 < EUO_LANES ? win[k][2] - x0 : EUO_LANES;
+            for (long l = 0; l < n; l++)
+              fill_frame_px(m, &bil, f, (int)(2 * (x0 + l) - ishift), (int)(2 * y - ishift),
+                            ithird, tmp[l]);
+            for (long l = 0; l < n; l++)
+              memcpy(sec + (y * S + x0 + l) * nch, tmp[l], sizeof(float) * nch);
+          }
       }
     }
   }

@@ -129,3 +129,25 @@ def test_random_multi_facet_jobs_bit_identical(seed):
                            f"{int((~same).sum())} of {same.size} words differ"
         for g in gs:
             g.release()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_device_setup_bit_identical(seed):
+    """source set-up ON THE DEVICE (container, bracing, prefilter with blocked
+    loads, spherical two-axis scheme, cubemap IR) against the oracle's, for
+    random sizes / degrees / channel counts: the coefficient arrays must be
+    bit-identical"""
+    rng = np.random.default_rng(9000 + seed)
+    for k in range(5):
+        sprj, sw, sh, shfov, nch, degree, *_ = draw_job(rng)
+        pdeg = int(rng.choice([degree, degree, 0, 1, 3, 5]))
+        img = jobs.synth_image(sw, sh, nch, seed=seed * 77 + k)
+        o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree, pdeg)
+        g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch), img, degree, pdeg)
+        got = g.download().reshape(-1)
+        ref = np.ascontiguousarray(o.container, np.float32).reshape(-1)
+        assert got.shape == ref.shape, (sprj, sw, sh, nch, degree, pdeg)
+        same = got.view(np.uint32) == ref.view(np.uint32)
+        assert same.all(), f"seed {seed} job {k}: prj {sprj} {sw}x{sh} fov {shfov:.1f} nch {nch} degree {degree} " \
+                           f"prefilter {pdeg}: {int((~same).sum())} of {same.size} coefficients differ"
+        g.release()
