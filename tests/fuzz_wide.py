@@ -9,7 +9,8 @@ import test_gpu_fuzz as F
 first, last = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, last):
-    for fn in (F.test_random_jobs_bit_identical, F.test_random_multi_facet_jobs_bit_identical):
+    for fn in (F.test_random_jobs_bit_identical, F.test_random_multi_facet_jobs_bit_identical,
+               F.test_random_device_setup_bit_identical):
         try:
             fn(seed)
         except AssertionError as e:
