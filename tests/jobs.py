@@ -45,7 +45,9 @@ class OracleSource:
 
     def __init__(self, prj, width, height, hfov_deg, pixels, spline_degree,
                  prefilter_degree=None, yaw=0.0, pitch=0.0, roll=0.0, brighten=1.0,
-                 support_min=8, tile=64, lens=None):
+                 support_min=8, tile=64, lens=None, window=None):
+        """window = (window_width, window_height, x_offset, y_offset): `pixels` is that
+        window of a width x height frame (a cropped PTO image, envutil_basic.h:447-470)"""
         if prefilter_degree is None:
             prefilter_degree = spline_degree
         hf = math.radians(hfov_deg)
@@ -56,6 +58,8 @@ class OracleSource:
         s.hfov = hf
         s.width, s.height = width, height
         s.window_width, s.window_height = width, height
+        if window is not None:
+            s.window_width, s.window_height, s.window_x_offset, s.window_y_offset = window
         s.yaw, s.pitch, s.roll = (math.radians(v) for v in (yaw, pitch, roll))
         s.brighten = brighten
         s.step = euo.lib().euo_get_step(prj, width, height, hf)

@@ -451,3 +451,31 @@ def test_column_invariant_longitude_paths(latlon, ypr, degree):
     for part in range(3):
         rows = ea.band_frame_rows(a.height, 8, 3, part)
         assert_bits(ea.render(a, g, 3, band=(8, 3, part)), ref[rows], "unpitched, bands")
+
+
+# ---- windowed sources (cropped PTO images) ------------------------------------------
+
+@pytest.mark.parametrize("sprj,shfov", [(euo.RECTILINEAR, 90.0), (euo.FISHEYE, 180.0), (euo.CYLINDRICAL, 200.0)])
+@pytest.mark.parametrize("window", [(120, 120, 40, 30), (90, 60, 0, 70), (200, 150, 0, 0)])
+def test_windowed_source_bit_exact(sprj, shfov, window):
+    """facet_spec.window_*: the image is a window of a larger frame
+    (envutil_basic.h:447-470); extents follow environment.h:617-633"""
+    ww, wh, xo, yo = window
+    img = jobs.synth_image(ww, wh, 3, seed=8)
+    o = jobs.OracleSource(sprj, 200, 150, shfov, img, 3, yaw=20, pitch=-10, window=window)
+    fct = ea.facet_spec(sprj, 200, 150, shfov, nchannels=3, yaw=20, pitch=-10, window=window)
+    g = ea.Source.adopt(fct, o.container, 3, o.bc[0], o.bc[1])
+    gl = ea.Source.load(fct, img, 3)
+    assert_bits(gl.download(), o.container, "windowed source, device set-up")
+    for tprj, tw, th, thfov in [(ea.SPHERICAL, 240, 120, 360.0), (ea.RECTILINEAR, 150, 110, 100.0)]:
+        for twine in (0, 2):
+            a = ea.arguments(tprj, tw, th, thfov, yaw=15, pitch=-5, spline_degree=3, twine=twine)
+            ref = jobs.oracle_render(a, o)
+            assert_bits(ea.render(a, g), ref, f"windowed source {window} prj {sprj} -> {tprj}")
+            assert (ref != 0).any()
+    # two windowed facets in one job
+    o2 = jobs.OracleSource(sprj, 200, 150, shfov, img, 3, yaw=-70, pitch=5, window=window)
+    g2 = ea.Source.adopt(ea.facet_spec(sprj, 200, 150, shfov, nchannels=3, yaw=-70, pitch=5, window=window),
+                         o2.container, 3, o2.bc[0], o2.bc[1])
+    a = ea.arguments(ea.SPHERICAL, 240, 120, 360.0, spline_degree=3)
+    assert_bits(ea.render(a, [g, g2], 3), jobs.oracle_render(a, [o, o2]), "windowed facets, synopsis")
