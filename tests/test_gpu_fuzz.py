@@ -142,12 +142,21 @@ def test_random_device_setup_bit_identical(seed):
         sprj, sw, sh, shfov, nch, degree, *_ = draw_job(rng)
         pdeg = int(rng.choice([degree, degree, 0, 1, 3, 5]))
         img = jobs.synth_image(sw, sh, nch, seed=seed * 77 + k)
-        o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree, pdeg)
-        g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch), img, degree, pdeg)
+        # cubemap IR geometry: --support_min / --tile_size (cubemap.h:233-400)
+        smin, tile = int(rng.choice([8, 8, 4, 12, 1])), int(rng.choice([64, 64, 16, 32]))
+        o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree, pdeg, support_min=smin, tile=tile)
+        g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch), img, degree, pdeg,
+                           support_min=smin, tile_size=tile)
         got = g.download().reshape(-1)
         ref = np.ascontiguousarray(o.container, np.float32).reshape(-1)
         assert got.shape == ref.shape, (sprj, sw, sh, nch, degree, pdeg)
         same = got.view(np.uint32) == ref.view(np.uint32)
         assert same.all(), f"seed {seed} job {k}: prj {sprj} {sw}x{sh} fov {shfov:.1f} nch {nch} degree {degree} " \
-                           f"prefilter {pdeg}: {int((~same).sum())} of {same.size} coefficients differ"
+                           f"prefilter {pdeg} support {smin} tile {tile}: {int((~same).sum())} of {same.size} " \
+                           "coefficients differ"
+        # and a render from the device-built source (pick-up geometry of that IR)
+        a = ea.arguments(ea.SPHERICAL, 96, 48, 360.0, yaw=float(rng.uniform(-180, 180)),
+                         pitch=float(rng.uniform(-60, 60)), spline_degree=degree)
+        got, ref = ea.render(a, g), jobs.oracle_render(a, o)
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all(), f"seed {seed} job {k}: render from device set-up"
         g.release()
