@@ -570,6 +570,20 @@ int eu_hip_source_load(const eu_facet *fct, const float *pixels, int spline_degr
   source_bcs(fct, &bc0, &bc1);
   eu_source *s = nullptr;
   if ((rc = new_source(fct, spline_degree, bc0, bc1, support_min, tile_size, &s))) return rc;
+  if (!is_cube(fct->projection)) {
+    // The device braces all frame slices at once from the core; zimt fills them one by one,
+    // outward, and for an image narrower than the spline's frame a slice is copied from
+    // slices filled before it (brace.h:134-330). Such images (a few pixels wide) are left
+    // to the host: prefilter there and hand the container over with eu_hip_source_adopt.
+    for (int a = 0; a < 2; a++) {
+      const long long m = s->geom.core[a], fr = std::max(s->geom.left[a], s->geom.right[a]);
+      if (m != 1 && m < fr + 1) {
+        (void)hipFree(s->dev);
+        delete s;
+        return fail(EU_ERR_UNSUPPORTED, "source narrower than the spline's frame: prefilter on the host and adopt");
+      }
+    }
+  }
   const int nch = s->nch;
   hipError_t e = hipSuccess;
   if (is_cube(fct->projection)) {

@@ -17,18 +17,24 @@ TRG_PRJ = [ea.SPHERICAL, ea.CYLINDRICAL, ea.RECTILINEAR, ea.STEREOGRAPHIC, ea.FI
            ea.BIATAN6]
 
 
+import os
+TINY = os.environ.get("EU_FUZZ_TINY") == "1"     # sources of a few pixels (tests/fuzz_wide.py)
+
+
 def draw_job(rng):
     sprj = SRC_PRJ[rng.integers(len(SRC_PRJ))]
     nch = int(rng.integers(1, 5))
     degree = int(rng.choice([0, 1, 1, 2, 3, 3, 4, 5]))
     if sprj in (euo.CUBEMAP, euo.BIATAN6):
-        face = int(rng.integers(16, 48))
+        face = int(rng.integers(2, 9)) if TINY else int(rng.integers(16, 48))
         sw, sh, shfov = face, 6 * face, 90.0
     else:
         sw, sh = int(rng.integers(24, 160)), int(rng.integers(24, 120))
+        if TINY:
+            sw, sh = int(rng.integers(1, 13)), int(rng.integers(1, 13))
         full = sprj in (euo.SPHERICAL, euo.CYLINDRICAL) and rng.random() < 0.5
         if sprj == euo.SPHERICAL and full:
-            sh = max(12, sw // 2)
+            sh = max(1 if TINY else 12, sw // 2)
             sw = 2 * sh
         shfov = 360.0 if full else float(rng.uniform(40.0, {euo.RECTILINEAR: 130.0, euo.STEREOGRAPHIC: 250.0,
                                                             euo.FISHEYE: 300.0}.get(sprj, 300.0)))
@@ -145,8 +151,13 @@ def test_random_device_setup_bit_identical(seed):
         # cubemap IR geometry: --support_min / --tile_size (cubemap.h:233-400)
         smin, tile = int(rng.choice([8, 8, 4, 12, 1])), int(rng.choice([64, 64, 16, 32]))
         o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree, pdeg, support_min=smin, tile=tile)
-        g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch), img, degree, pdeg,
-                           support_min=smin, tile_size=tile)
+        try:
+            g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch), img, degree, pdeg,
+                               support_min=smin, tile_size=tile)
+        except ea.EuError as e:
+            # images narrower than the spline's frame are left to the host (eu_api.hip)
+            assert "-3" in str(e) and min(sw, sh) <= 6, str(e)
+            continue
         got = g.download().reshape(-1)
         ref = np.ascontiguousarray(o.container, np.float32).reshape(-1)
         assert got.shape == ref.shape, (sprj, sw, sh, nch, degree, pdeg)
