@@ -126,10 +126,24 @@ def test_random_multi_facet_jobs_bit_identical(seed):
         else:
             tw, th = int(rng.integers(1, 150)), int(rng.integers(1, 70))
             thfov = float(rng.uniform(30.0, {ea.RECTILINEAR: 140.0, ea.STEREOGRAPHIC: 300.0}.get(tprj, 360.0)))
+        kw = {}
+        if rng.random() < 0.3 and tw >= 4 and th >= 4:
+            x0, y0 = int(rng.integers(0, tw // 2)), int(rng.integers(0, th // 2))
+            kw["crop"] = (x0, int(rng.integers(x0 + 1, tw + 1)), y0, int(rng.integers(y0 + 1, th + 1)))
+        if rng.random() < 0.25:
+            kw["tethered"] = True
         a = ea.arguments(tprj, tw, th, thfov, yaw=float(rng.uniform(-180, 180)),
                          pitch=float(rng.uniform(-90, 90)), roll=float(rng.uniform(-180, 180)),
-                         spline_degree=degree, twine=int(rng.choice([0, 0, 2])))
-        got, ref = ea.render(a, gs, out_n), jobs.oracle_render(a, os_, nch=out_n)
+                         spline_degree=degree, twine=int(rng.choice([0, 0, 2])), **kw)
+        ref = jobs.oracle_render(a, os_, nch=out_n)
+        if rng.random() < 0.3:
+            cnt = int(rng.integers(2, 5))
+            band = (int(rng.choice([4, 8, 16])), cnt, int(rng.integers(0, cnt)))
+            got = ea.render(a, gs, out_n, band=band)
+            ref = ref[ea.band_frame_rows(a.out_height, *band)]
+        else:
+            got = ea.render(a, gs, out_n)
+        assert got.shape == ref.shape
         same = got.view(np.uint32) == ref.view(np.uint32)
         assert same.all(), f"seed {seed} job {k}: {nf} facets deg {degree} out {out_n} trg {tprj} {tw}x{th}: " \
                            f"{int((~same).sum())} of {same.size} words differ"
