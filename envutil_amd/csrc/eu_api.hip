@@ -55,6 +55,12 @@ struct context {
   size_t col_cap = 0, row_cap = 0, taps_cap = 0;
   float *lut = nullptr;        // to_screen_t's sRGB LUT, 257 floats
   float *scr = nullptr; size_t scr_cap = 0;       // float frame of a tethered job
+  // host copies of the plan's stepper tables and, from them, the layout the packed
+  // kernel should use per segment of EU_SEG_ROWS frame rows (launch-level hybrid)
+  std::vector<float> h_col, h_row;
+  std::vector<unsigned char> seg_flags;
+  bool seg_valid = false, seg_mixed = false;
+  eu_src_dev seg_sd;
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
   // the tables of the last target stay valid while (target geometry,
   // orientation, taps) repeat: streaming / tethered jobs re-render the same
@@ -357,6 +363,9 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     form = g.plan_form = tb.form;
     norm_mode = g.plan_norm = tb.norm_mode;
     g.plan_key.swap(key);
+    g.h_col.swap(tb.col);
+    g.h_row.swap(tb.row);
+    g.seg_valid = false;
   }
   memset(p, 0, sizeof *p);
   p->width = frame_w(t); p->height = frame_h(t);
@@ -465,12 +474,99 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   return EU_OK;
 }
 
+// Launch-level hybrid of the packed kernel's two work layouts. Where source rows run
+// ACROSS target rows (the inner half of the polar faces of a cubemap made from a lat/lon
+// image: 0.098 -> 0.071 ms per 1024 rows) 32x16 tiles beat the 128x4 row strips; everywhere
+// else the strips win (0.045 vs 0.055 ms). The frame is cut into segments of EU_SEG_ROWS
+// rows; 16 probe pixels per segment, evaluated on the host from the plan's stepper
+// tables, say how the source rows run there. Lat/lon sources only.
+#define EU_SEG_ROWS 512
+
+void compute_seg_flags(const eu_render_params *p)
+{
+  const int W = p->width, H = p->height;
+  const int nseg = (H + EU_SEG_ROWS - 1) / EU_SEG_ROWS;
+  g.seg_flags.assign((size_t)nseg, 0);
+  g.seg_mixed = false;
+  const eu_src_dev &s = p->src;
+  if (s.prj != EU_SPHERICAL || W < 64 || g.h_col.size() < (size_t)2 * W || g.h_row.size() < (size_t)H * EU_ROW_FLOATS)
+    return;
+  const double kx = (double)s.total_w / s.ext_w, ky = (double)s.total_h / s.ext_h;   // pixels per radian
+  auto ray = [&](int x, int y, double *r) {
+    const float *rt = &g.h_row[(size_t)y * EU_ROW_FLOATS];
+    const float c0 = g.h_col[(size_t)x], c1 = g.h_col[(size_t)W + x];
+    for (int i = 0; i < 3; i++)
+      r[i] = p->form == EU_FORM_BCA ? (double)rt[3 + i] * c0 + (double)rt[6 + i] * c1 + rt[i]
+                                    : (double)rt[3 + i] * c0 + rt[i];
+  };
+  int any = 0;
+  for (int k = 0; k < nseg; k++) {
+    const int yc = std::min(k * EU_SEG_ROWS + EU_SEG_ROWS / 2, H - 1);
+    int across = 0;
+    for (int j = 0; j < 16; j++) {
+      const int xc = std::min((int)((j + 0.5) * W / 16), W - 2);
+      double a[3], b[3];
+      ray(xc, yc, a);
+      ray(xc + 1, yc, b);
+      const double lon0 = std::atan2(a[0], a[2]), lon1 = std::atan2(b[0], b[2]);
+      const double lat0 = std::atan2(a[1], std::hypot(a[0], a[2])), lat1 = std::atan2(b[1], std::hypot(b[0], b[2]));
+      double dlon = std::fabs(lon1 - lon0);
+      if (dlon > M_PI) dlon = 2.0 * M_PI - dlon;
+      if (std::fabs(lat1 - lat0) * ky > 0.5 * dlon * kx) across++;
+    }
+    g.seg_flags[(size_t)k] = across > 8;
+    any += across > 8;
+  }
+  g.seg_mixed = any > 0;
+}
+
 // the packed two-pixel kernel where it applies, the general kernel otherwise
 // (EU_HIP_KERNEL=1 forces the general kernel: A/B switch)
 int launch_render(const eu_render_params *p, void *st)
 {
   static const int force_v1 = [] { const char *e = getenv("EU_HIP_KERNEL"); return e && e[0] == '1'; }();
+  static const bool hybrid = [] { const char *e = getenv("EU_HIP_HYBRID"); return !(e && e[0] == '0'); }();
   if (!force_v1) {
+    // worth it for big launches of cubic / quadratic jobs only: every run is a launch of
+    // its own (a rank's share of an 8-way split, or a 0.2 ms bilinear job, loses more to
+    // the extra launches than the layout gains); EU_HIP_HYBRID=2 lifts the size limit (tests)
+    static const bool hybrid_any = [] { const char *e = getenv("EU_HIP_HYBRID"); return e && e[0] == '2'; }();
+    const bool big = hybrid_any || (p->src.degree >= 2 &&
+                                    (long long)(p->row_end - p->row_begin) * p->width >= (1LL << 25));
+    if (hybrid && big && !p->twine && p->stage == 0 && p->norm_mode == EU_NORM_NONE && p->src.prj == EU_SPHERICAL) {
+      eu_src_dev cmp = p->src;
+      cmp.base = nullptr;
+      if (!g.seg_valid || memcmp(&cmp, &g.seg_sd, sizeof cmp)) {
+        compute_seg_flags(p);
+        g.seg_sd = cmp;
+        g.seg_valid = true;
+      }
+      if (g.seg_mixed) {
+        // runs of local rows whose segments want the same layout, in chunks of 64 rows
+        int a = p->row_begin;
+        auto flag_of = [&](int r) {
+          const int fy = eu_frame_row(std::min(r, p->row_end - 1), p->band_shift, p->band_count, p->band_index);
+          return (int)g.seg_flags[(size_t)std::min(fy / EU_SEG_ROWS, (int)g.seg_flags.size() - 1)];
+        };
+        while (a < p->row_end) {
+          const int fl = flag_of(a);
+          int b = std::min((a / 64 + 1) * 64, p->row_end);
+          while (b < p->row_end && flag_of(b) == fl) b = std::min(b + 64, p->row_end);
+          eu_render_params q = *p;
+          q.row_begin = a; q.row_end = b;
+          q.out = p->out + (long long)(a - p->row_begin) * p->out_stride;
+          q.layout = fl ? 2 : 1;
+          const int rc = eu_launch_render2(&q, st);
+          if (rc > 0) {                 // not a packed-kernel job after all: one ordinary launch
+            if (a != p->row_begin) return -1;
+            return eu_launch_render(p, st);
+          }
+          if (rc < 0) return rc;
+          a = b;
+        }
+        return 0;
+      }
+    }
     int rc = eu_launch_render2(p, st);
     if (rc <= 0) return rc;
   }

@@ -574,7 +574,8 @@ static int launch2_ndp(const eu_render_params &p, hipStream_t st)
 {
   // EU_HIP_LDS: 0 = row-strip tiles (eu_render2_kernel), 1 = 32x16 tiles staged
   // through LDS, 2 = 32x16 tiles with direct gathers
-  static const int use_lds = [] { const char *e = getenv("EU_HIP_LDS"); return e ? atoi(e) : 0; }();
+  static const int env_lds = [] { const char *e = getenv("EU_HIP_LDS"); return e ? atoi(e) : 0; }();
+  const int use_lds = p.layout == 1 ? 0 : p.layout == 2 ? 2 : env_lds;
   if (!p.twine && use_lds && p.norm_mode == EU_NORM_NONE) {
     eu_render_params q = p;
     q.tiles_x = (p.width + EU3_TW - 1) / EU3_TW;
