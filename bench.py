@@ -281,7 +281,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic,
-                     "kernel": "eu_render_multi_kernel" if nsrcs > 1 else ("eu_render2_kernel (packed two-pixel)" if (sprj in (0, 5, 6) and degree in (1, 2, 3)) else "eu_render_kernel"), "kernel_ms": round(kernel_ms, 4),
+                     "kernel": "eu_render_multi_kernel" if nsrcs > 1 else ("eu_render2_kernel (packed two-pixel; big cubic lat/lon jobs: + eu_render3_kernel on the row runs where source rows run across, launch-level layout choice)" if (sprj in (0, 5, 6) and degree in (1, 2, 3)) else "eu_render_kernel"), "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": alg_bytes},
     }
 
