@@ -155,9 +155,19 @@ def main():
     # this rank's rows: interleaved bands of BAND_ROWS rows dealt round-robin
     # (rows differ in cost - the polar cube faces take 1.7x the others - so
     # contiguous strips would leave 8 GPUs at 5.6x, tools/strip_times.py)
-    from envutil_amd.distributed import gather_bands
+    # ... unless the library can say which rows are the expensive ones (lat/lon source,
+    # cubic taps: the segments it renders with the tile layout): then contiguous strips
+    # of equal estimated cost, on which the launch-level layout choice keeps working
+    from envutil_amd.distributed import gather_bands, gather_ranges, cost_partition
     band = (BAND_ROWS, world, rank) if world > 1 else None
     r0, r1 = 0, ea.band_rows(th, BAND_ROWS, world, rank) if world > 1 else th
+    ranges = None
+    if world > 1 and degree >= 2 and not twine and len(sources) == 1:
+        seg_rows, flags = ea.layout_segments(args, sources, nch)
+        if flags.size and flags.any():
+            ranges = cost_partition(th, world, seg_rows, flags)
+            band = None
+            r0, r1 = ranges[rank]
     out = torch.empty(((r1 - r0), tw, nch), device=dev, dtype=torch.float32)
     srcs = (C.c_void_p * len(sources))(*[x.handle for x in sources])
     nsrcs = len(sources)
@@ -197,7 +207,10 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        frame = gather_bands(dist, out, th, tw, nch, rank, world, BAND_ROWS, dst=0)
+        if ranges is not None:
+            frame = gather_ranges(dist, out, ranges, th, tw, nch, rank, world, dst=0)
+        else:
+            frame = gather_bands(dist, out, th, tw, nch, rank, world, BAND_ROWS, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         gather_ms = 1e3 * (time.perf_counter() - tg)
@@ -272,7 +285,9 @@ def main():
         "config": {"workload": WORKLOAD_TEXT[a.workload], "name": a.workload,
                    "channels": nch, "spline_degree": degree, "twine": twine,
                    "rows_per_gpu": r1 - r0,
-                   "tiling": "whole frame" if world == 1 else f"bands of {BAND_ROWS} rows, round-robin over {world} ranks",
+                   "tiling": "whole frame" if world == 1 else (
+                       f"contiguous strips of equal estimated cost over {world} ranks" if ranges is not None
+                       else f"bands of {BAND_ROWS} rows, round-robin over {world} ranks"),
                    "gather_ms_untimed": None if gather_ms is None else round(gather_ms, 3),
                    "setup_s": round(t_setup, 2),
                    "host_boundary": {"source_load_s": round(t_load, 3),

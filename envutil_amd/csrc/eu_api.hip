@@ -527,13 +527,13 @@ int launch_render(const eu_render_params *p, void *st)
   static const int force_v1 = [] { const char *e = getenv("EU_HIP_KERNEL"); return e && e[0] == '1'; }();
   static const bool hybrid = [] { const char *e = getenv("EU_HIP_HYBRID"); return !(e && e[0] == '0'); }();
   if (!force_v1) {
-    // worth it for big launches of cubic / quadratic jobs only: every run is a launch of
-    // its own (a rank's share of an 8-way split, or a 0.2 ms bilinear job, loses more to
-    // the extra launches than the layout gains); EU_HIP_HYBRID=2 lifts the size limit (tests)
+    // worth it for cubic / quadratic jobs whose rows fall into a few long runs: every run
+    // is a launch of its own (a rank's share of a band-interleaved split has many short
+    // runs, a 0.2 ms bilinear job little to gain: both lose more to the extra launches
+    // than the layout gains); EU_HIP_HYBRID=2 lifts the limits (tests)
     static const bool hybrid_any = [] { const char *e = getenv("EU_HIP_HYBRID"); return e && e[0] == '2'; }();
-    const bool big = hybrid_any || (p->src.degree >= 2 &&
-                                    (long long)(p->row_end - p->row_begin) * p->width >= (1LL << 25));
-    if (hybrid && big && !p->twine && p->stage == 0 && p->norm_mode == EU_NORM_NONE && p->src.prj == EU_SPHERICAL) {
+    const bool worth = hybrid_any || p->src.degree >= 2;
+    if (hybrid && worth && !p->twine && p->stage == 0 && p->norm_mode == EU_NORM_NONE && p->src.prj == EU_SPHERICAL) {
       eu_src_dev cmp = p->src;
       cmp.base = nullptr;
       if (!g.seg_valid || memcmp(&cmp, &g.seg_sd, sizeof cmp)) {
@@ -541,17 +541,32 @@ int launch_render(const eu_render_params *p, void *st)
         g.seg_sd = cmp;
         g.seg_valid = true;
       }
-      if (g.seg_mixed) {
-        // runs of local rows whose segments want the same layout, in chunks of 64 rows
+      // runs of local rows whose segments want the same layout, in chunks of 64 rows
+      auto flag_of = [&](int r) {
+        const int fy = eu_frame_row(std::min(r, p->row_end - 1), p->band_shift, p->band_count, p->band_index);
+        return (int)g.seg_flags[(size_t)std::min(fy / EU_SEG_ROWS, (int)g.seg_flags.size() - 1)];
+      };
+      auto run_end = [&](int a, int fl) {
+        int b = std::min((a / 64 + 1) * 64, p->row_end);
+        while (b < p->row_end && flag_of(b) == fl) b = std::min(b + 64, p->row_end);
+        return b;
+      };
+      int nruns = 0, tiled = 0, shortest = INT_MAX;
+      if (g.seg_mixed)
+        for (int a = p->row_begin; a < p->row_end; nruns++) {
+          const int fl = flag_of(a);
+          tiled += fl;
+          const int b = run_end(a, fl);
+          shortest = std::min(shortest, b - a);
+          a = b;
+        }
+      // a few long runs (the whole frame: 5; a contiguous strip of a split: 1-3), not the
+      // many short ones of a band-interleaved share (0.18 -> 0.21 ms when split up)
+      if (tiled > 0 && (hybrid_any || nruns <= 3 || (nruns <= 5 && shortest >= EU_SEG_ROWS))) {
         int a = p->row_begin;
-        auto flag_of = [&](int r) {
-          const int fy = eu_frame_row(std::min(r, p->row_end - 1), p->band_shift, p->band_count, p->band_index);
-          return (int)g.seg_flags[(size_t)std::min(fy / EU_SEG_ROWS, (int)g.seg_flags.size() - 1)];
-        };
         while (a < p->row_end) {
           const int fl = flag_of(a);
-          int b = std::min((a / 64 + 1) * 64, p->row_end);
-          while (b < p->row_end && flag_of(b) == fl) b = std::min(b + 64, p->row_end);
+          const int b = run_end(a, fl);
           eu_render_params q = *p;
           q.row_begin = a; q.row_end = b;
           q.out = p->out + (long long)(a - p->row_begin) * p->out_stride;
@@ -829,6 +844,36 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
                           hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return EU_OK;
+}
+
+// the layout choice per segment of the (cropped) frame for this job: flags[k] = 1 where
+// rows [k * seg_rows, (k + 1) * seg_rows) render faster - and cost about 1.55x the others -
+// with the tile layout; returns the number of segments (0: no lat/lon source / no table)
+int eu_hip_layout_segments(const eu_target *trg, eu_source *const *srcs, int nsrc,
+                           unsigned char *flags, int max_flags, int *seg_rows)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if (!trg || !srcs || nsrc != 1 || !srcs[0] || !flags) return fail(EU_ERR_ARGUMENT, "one source, flags buffer");
+  eu_render_params p;
+  eu_target t = *trg;
+  t.band_rows = 0; t.band_count = 0; t.band_index = 0;
+  t.row_begin = 0; t.row_end = frame_h(trg);
+  float dummy;
+  if ((rc = build_params(&t, srcs, 1, &dummy, (size_t)frame_w(trg) * t.nchannels * sizeof(float), &p))) return rc;
+  if (seg_rows) *seg_rows = EU_SEG_ROWS;
+  if (p.twine || p.norm_mode != EU_NORM_NONE || p.src.prj != EU_SPHERICAL) return 0;
+  eu_src_dev cmp = p.src;
+  cmp.base = nullptr;
+  if (!g.seg_valid || memcmp(&cmp, &g.seg_sd, sizeof cmp)) {
+    compute_seg_flags(&p);
+    g.seg_sd = cmp;
+    g.seg_valid = true;
+  }
+  const int n = (int)g.seg_flags.size();
+  if (n > max_flags) return fail(EU_ERR_ARGUMENT, "flags buffer too small");
+  memcpy(flags, g.seg_flags.data(), (size_t)n);
+  return n;
 }
 
 int eu_hip_band_rows(int height, int band_rows, int band_count, int band_index)

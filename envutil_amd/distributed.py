@@ -92,3 +92,53 @@ def gather_bands(dist, strip, height, width, nch, rank, world_size, band_rows, d
     if strip.shape[0] > 0:
         dist.send(strip.contiguous(), dst=dst)
     return None
+
+
+# ---- contiguous strips of equal estimated cost --------------------------------------
+# Where the library can say which rows are the expensive ones (eu_hip_layout_segments:
+# the segments it renders with the tile layout: 1.55x the time of the others, 2x counting
+# the extra launches they break a strip into - measured, tools/strip_times.py) a
+# frame is better cut into CONTIGUOUS strips of equal cost than dealt out in bands: every
+# rank then has a few long runs of one layout and the launch-level layout choice applies
+# to it (it does not for the many short runs of a band-interleaved share).
+
+def cost_partition(height, world_size, seg_rows, flags, flag_cost=2.0, align=64):
+    """[(r0, r1)] for every rank: contiguous, covering, boundaries at multiples of
+    `align`, cumulative cost (1 per row, flag_cost per row of a flagged segment) split
+    evenly. Deterministic: every rank computes the same list."""
+    import numpy as np
+    w = np.ones(height, np.float64)
+    for k, f in enumerate(np.asarray(flags).tolist()):
+        if f:
+            w[k * seg_rows:(k + 1) * seg_rows] = flag_cost
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    bounds = [0]
+    for r in range(1, world_size):
+        y = int(np.searchsorted(cum, cum[-1] * r / world_size))
+        y = int(round(y / align)) * align
+        bounds.append(min(max(y, bounds[-1]), height))
+    bounds.append(height)
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+def gather_ranges(dist, strip, ranges, height, width, nch, rank, world_size, dst=0):
+    """collect every rank's rows [ranges[r][0], ranges[r][1]) on `dst`; returns the frame
+    there, None elsewhere"""
+    import torch
+    if world_size == 1:
+        return strip
+    if rank == dst:
+        frame = torch.empty((height, width, nch), dtype=strip.dtype, device=strip.device)
+        r0, r1 = ranges[rank]
+        frame[r0:r1].copy_(strip)
+        reqs = []
+        for r in range(world_size):
+            q0, q1 = ranges[r]
+            if r != dst and q1 > q0:
+                reqs.append(dist.irecv(frame[q0:q1], src=r))
+        for q in reqs:
+            q.wait()
+        return frame
+    if strip.shape[0] > 0:
+        dist.send(strip.contiguous(), dst=dst)
+    return None

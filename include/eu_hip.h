@@ -114,6 +114,15 @@ typedef struct eu_target {
   int32_t band_rows, band_count, band_index;
 } eu_target;
 
+/* How the library would lay the job's rows out (eu_api.hip: launch-level choice between
+ * row strips and 32x16 tiles): flags[k] = 1 for segment k of *seg_rows frame rows where
+ * source rows run across target rows - those rows take about 1.55x the time of the others,
+ * about 2x when they are part of a strip they break into several launches. For hosts that
+ * split a frame into CONTIGUOUS strips of equal cost. Returns the number of segments
+ * (0 when the job has no such structure) or a negative eu_status. */
+int  eu_hip_layout_segments(const eu_target *trg, eu_source *const *srcs, int nsrc,
+                            unsigned char *flags, int max_flags, int *seg_rows);
+
 /* number of local rows of part band_index (see eu_target.band_*) in a frame of
  * `height` rows; height itself when band_count <= 1 */
 int  eu_hip_band_rows(int height, int band_rows, int band_count, int band_index);

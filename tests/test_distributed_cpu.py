@@ -49,6 +49,28 @@ def test_band_rows_cover_without_overlap():
                     assert max(sizes) - min(sizes) <= br
 
 
+def test_cost_partition_covers_and_balances():
+    """contiguous strips of equal estimated cost (distributed.cost_partition)"""
+    from envutil_amd.distributed import cost_partition
+    flags = np.zeros(48, np.uint8)
+    flags[18:22] = 1
+    flags[26:30] = 1                                  # the headline job's flagged segments
+    for world in (1, 2, 3, 4, 8):
+        rg = cost_partition(24576, world, 512, flags)
+        assert rg[0][0] == 0 and rg[-1][1] == 24576 and len(rg) == world
+        cost = []
+        for (a, b), nxt in zip(rg, rg[1:] + [(24576, 24576)]):
+            assert a <= b and b == nxt[0] and a % 64 == 0
+            w = np.ones(24576)
+            for k in np.flatnonzero(flags):
+                w[k * 512:(k + 1) * 512] = 2.0
+            cost.append(w[a:b].sum())
+        assert max(cost) - min(cost) <= 2 * 64 * 2.0 + 1e-9, cost
+    # no flags: equal row counts; odd heights
+    rg = cost_partition(1000, 3, 512, np.zeros(2, np.uint8))
+    assert rg[0][0] == 0 and rg[-1][1] == 1000 and all(a <= b for a, b in rg)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -80,12 +102,19 @@ def _worker(rank, world, port, q):
         mine = torch.from_numpy(np.concatenate(bands))
         assert mine.shape[0] == ea.band_rows(a.height, 8, world, rank)
         frame2 = gather_bands(dist, mine, a.height, a.width, 3, rank, world, 8)
+        # and as contiguous strips of equal estimated cost (an arbitrary flag pattern)
+        from envutil_amd.distributed import cost_partition, gather_ranges
+        ranges = cost_partition(a.height, world, 16, np.array([0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0], np.uint8), align=4)
+        c0, c1 = ranges[rank]
+        mine3 = torch.from_numpy(jobs.oracle_render(a, o, row_begin=c0, row_end=c1, nthreads=2))
+        frame3 = gather_ranges(dist, mine3, ranges, a.height, a.width, 3, rank, world)
         if rank == 0:
             whole = jobs.oracle_render(a, jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img, 3), nthreads=2)
             q.put(bool((frame.numpy().view(np.uint32) == whole.view(np.uint32)).all()) and
-                  bool((frame2.numpy().view(np.uint32) == whole.view(np.uint32)).all()))
+                  bool((frame2.numpy().view(np.uint32) == whole.view(np.uint32)).all()) and
+                  bool((frame3.numpy().view(np.uint32) == whole.view(np.uint32)).all()))
         else:
-            q.put(frame is None and frame2 is None)
+            q.put(frame is None and frame2 is None and frame3 is None)
     finally:
         dist.destroy_process_group()
 

@@ -80,3 +80,34 @@ def test_full_size_tilings_reassemble(headline):
         ea.lib().eu_hip_sync()
         frame[r0:r1] = out
     assert torch.equal(frame.view(torch.int32), whole.view(torch.int32))
+
+
+def test_full_size_cost_partition_and_layout_segments(headline):
+    """what bench.py does for N > 1 on this job: the library's layout segments, strips of
+    equal estimated cost, every strip rendered (with the launch-level layout choice) and
+    put back: the single-launch frame"""
+    import torch
+    from envutil_amd.distributed import cost_partition
+    src, args = headline
+    dev = torch.device("cuda:0")
+    th, tw, nch = 24576, 4096, 3
+    seg_rows, flags = ea.layout_segments(args, src, nch)
+    assert seg_rows == 512 and flags.size == th // 512
+    # the inner halves of the two polar faces, nothing on the equatorial faces
+    assert flags[18:22].all() and flags[26:30].all() and not flags[:16].any() and not flags[32:].any()
+
+    def on_device(r0, r1):
+        out = torch.empty((r1 - r0, tw, nch), device=dev, dtype=torch.float32)
+        t = args.target(nch, r0, r1, 0)
+        arr = (ea.api.C.c_void_p * 1)(src.handle)
+        assert ea.lib().eu_hip_render(ea.api.C.byref(t), arr, 1, ea.api.C.c_void_p(out.data_ptr()),
+                                      tw * nch * 4, 1, None) == 0
+        ea.lib().eu_hip_sync()
+        return out
+
+    whole = on_device(0, th)
+    for world in (2, 8):
+        frame = torch.full_like(whole, float("nan"))
+        for r0, r1 in cost_partition(th, world, seg_rows, flags):
+            frame[r0:r1] = on_device(r0, r1)
+        assert torch.equal(frame.view(torch.int32), whole.view(torch.int32))

@@ -31,6 +31,16 @@ for world in (2, 4, 8):
         band = (bench.BAND_ROWS, world, r)
         ts.append(round(ea.render_timed(args, src, out.data_ptr(), 10, nch, band=band), 4))
     res[f"n{world}_bands"] = {"part_ms": ts, "predicted_speedup": round(full / max(ts), 2)}
+# contiguous strips of equal estimated cost (what bench.py uses when the library reports
+# layout segments): the launch-level layout choice applies inside every strip
+from envutil_amd.distributed import cost_partition
+seg_rows, flags = ea.layout_segments(args, src, nch)
+if flags.size and flags.any():
+    for fc in [float(v) for v in os.environ.get("EU_FLAG_COSTS", "2.0").split(",")]:
+        for world in (2, 4, 8):
+            ts = [round(ea.render_timed(args, src, out.data_ptr(), 10, nch, r0, r1), 4)
+                  for r0, r1 in cost_partition(th, world, seg_rows, flags, flag_cost=fc)]
+            res[f"n{world}_cost_{fc}"] = {"strip_ms": ts, "predicted_speedup": round(full / max(ts), 2)}
 faces = [round(ea.render_timed(args, src, out.data_ptr(), 10, nch, f * tw, (f + 1) * tw), 4) for f in range(6)]
 res["face_ms"] = faces
 print(json.dumps(res))
