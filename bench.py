@@ -188,6 +188,8 @@ def main():
     for _ in range(a.warmup):
         step()
     sync_all()
+    ea.lib().eu_hip_launch_count.restype = C.c_ulonglong
+    launches0 = ea.lib().eu_hip_launch_count()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -196,6 +198,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    launches_per_step = (ea.lib().eu_hip_launch_count() - launches0) / a.steps if nsrcs == 1 else 1
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -297,6 +300,7 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic,
                      "kernel": "eu_render_multi_kernel" if nsrcs > 1 else ("eu_render2_kernel (packed two-pixel; big cubic lat/lon jobs: + eu_render3_kernel on the row runs where source rows run across, launch-level layout choice)" if (sprj in (0, 5, 6) and degree in (1, 2, 3)) else "eu_render_kernel"), "kernel_ms": round(kernel_ms, 4),
+                     "launches_per_step": launches_per_step,
                      "algorithmic_bytes": alg_bytes},
     }
 

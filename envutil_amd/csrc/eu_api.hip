@@ -60,6 +60,7 @@ struct context {
   std::vector<float> h_col, h_row;
   std::vector<unsigned char> seg_flags;
   bool seg_valid = false, seg_mixed = false;
+  unsigned long long launches = 0;                // render kernel launches so far
   eu_src_dev seg_sd;
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
   // the tables of the last target stay valid while (target geometry,
@@ -571,6 +572,7 @@ int launch_render(const eu_render_params *p, void *st)
           q.row_begin = a; q.row_end = b;
           q.out = p->out + (long long)(a - p->row_begin) * p->out_stride;
           q.layout = fl ? 2 : 1;
+          g.launches++;
           const int rc = eu_launch_render2(&q, st);
           if (rc > 0) {                 // not a packed-kernel job after all: one ordinary launch
             if (a != p->row_begin) return -1;
@@ -582,9 +584,12 @@ int launch_render(const eu_render_params *p, void *st)
         return 0;
       }
     }
+    g.launches++;
     int rc = eu_launch_render2(p, st);
     if (rc <= 0) return rc;
+    g.launches--;
   }
+  g.launches++;
   return eu_launch_render(p, st);
 }
 
@@ -875,6 +880,10 @@ int eu_hip_layout_segments(const eu_target *trg, eu_source *const *srcs, int nsr
   memcpy(flags, g.seg_flags.data(), (size_t)n);
   return n;
 }
+
+// render kernel launches of this process so far (a render step of a big cubic job is
+// several: launch-level layout choice); lets a benchmark report launches per step
+unsigned long long eu_hip_launch_count(void) { return g.launches; }
 
 int eu_hip_band_rows(int height, int band_rows, int band_count, int band_index)
 {

@@ -123,6 +123,9 @@ typedef struct eu_target {
 int  eu_hip_layout_segments(const eu_target *trg, eu_source *const *srcs, int nsrc,
                             unsigned char *flags, int max_flags, int *seg_rows);
 
+/* render kernel launches issued so far by this process (single-facet path) */
+unsigned long long eu_hip_launch_count(void);
+
 /* number of local rows of part band_index (see eu_target.band_*) in a frame of
  * `height` rows; height itself when band_count <= 1 */
 int  eu_hip_band_rows(int height, int band_rows, int band_count, int band_index);
