@@ -287,8 +287,17 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
   }
 }
 
+// The synopsis kernels are bound by the latency of their gathers (six 1-GB sources,
+// little locality) more than by anything else: capping the registers for 5 waves per
+// SIMD (a few spills) beats the 2-3 waves the allocator settles on by itself - config 5:
+// 9.2 ms free, 8.0 at 4, 7.7 at 5, 8.8 at 6, 11.7 at 8 waves.
+#ifndef EU_MULTI_WAVES
+#define EU_MULTI_WAVES 5
+#endif
+#define EU_MULTI_OCC __attribute__((amdgpu_waves_per_eu(EU_MULTI_WAVES, EU_MULTI_WAVES)))
+
 template <int NCH, int DEG, bool PLUS>
-__global__ __launch_bounds__(256) void eu_render_multi_kernel(const eu_multi_params p)
+__global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const eu_multi_params p)
 {
   extern __shared__ float eu_dyn_lds[];
   const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
