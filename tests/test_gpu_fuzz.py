@@ -44,6 +44,8 @@ def draw_job(rng):
         th, thfov = 6 * tw, 90.0
     else:
         tw, th = int(rng.integers(1, 200)), int(rng.integers(1, 90))
+        if rng.random() < 0.15:                      # rows longer than one and two 512-pixel segments
+            tw, th = int(rng.integers(500, 1300)), int(rng.integers(1, 12))
         thfov = float(rng.uniform(30.0, {ea.RECTILINEAR: 140.0, ea.STEREOGRAPHIC: 300.0}.get(tprj, 360.0)))
     kw = dict(yaw=float(rng.uniform(-180, 180)), pitch=float(rng.uniform(-90, 90)),
               roll=float(rng.uniform(-180, 180)), spline_degree=degree,
