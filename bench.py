@@ -104,14 +104,23 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available() or ea.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    # EU_BENCH_REHEARSE=1: the N-rank logic on however many GPUs there are (all ranks may
+    # share one), gloo instead of RCCL, host-staged transfers, and a check of the gathered
+    # frame against a single launch - a rehearsal of the multi-GPU path, not a measurement
+    rehearse = os.environ.get("EU_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     ea.lib().eu_hip_init(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=dev)
 
     (sname, sw, sh, shfov), (tname, tw, th, thfov), nch, degree, twine, ypr = WORKLOADS[a.workload]
     from envutil_amd.api import PROJECTION_NAMES
@@ -144,7 +153,14 @@ def main():
         if world > 1:
             ptr, n = s1.device_ptr()
             buf = torch.as_tensor(_DevBuf(ptr, n), device=dev)
-            dist.broadcast(buf, 0)                       # RCCL over xGMI, once per source
+            if rehearse:
+                hb = buf.cpu()
+                dist.broadcast(hb, 0)
+                if rank != 0:
+                    buf.copy_(hb)
+                del hb
+            else:
+                dist.broadcast(buf, 0)                   # RCCL over xGMI, once per source
             torch.cuda.synchronize()
         sources.append(s1)
     src = sources[0]
@@ -200,7 +216,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launches_per_step = (ea.lib().eu_hip_launch_count() - launches0) / a.steps if nsrcs == 1 else 1
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -210,13 +226,23 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
+        gsrc = out.cpu() if rehearse else out
         if ranges is not None:
-            frame = gather_ranges(dist, out, ranges, th, tw, nch, rank, world, dst=0)
+            frame = gather_ranges(dist, gsrc, ranges, th, tw, nch, rank, world, dst=0)
         else:
-            frame = gather_bands(dist, out, th, tw, nch, rank, world, BAND_ROWS, dst=0)
+            frame = gather_bands(dist, gsrc, th, tw, nch, rank, world, BAND_ROWS, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         gather_ms = 1e3 * (time.perf_counter() - tg)
+        if rehearse and rank == 0:
+            whole = torch.empty((th, tw, nch), device=dev, dtype=torch.float32)
+            tw_ = args.target(nch, 0, th, 0)
+            rc = ea.lib().eu_hip_render(C.byref(tw_), srcs, nsrcs, C.c_void_p(whole.data_ptr()),
+                                        tw * nch * 4, 1, None)
+            ea.lib().eu_hip_sync()
+            same = rc == 0 and torch.equal(whole.cpu().view(torch.int32), frame.view(torch.int32))
+            print(f"REHEARSAL world {world}: gathered frame identical to a single launch: {same}", file=sys.stderr)
+            del whole
         del frame
 
     # ---- kernel-only time with HIP events on the kernel's stream ------------
