@@ -83,6 +83,23 @@ struct context {
       return fail(EU_ERR_NO_DEVICE, std::string(#call ": ") + hipGetErrorString(e_)); \
   } while (0)
 
+// per-device state: the library's stream and to_screen_t's sRGB LUT. Used by the implicit
+// initialisation and by eu_hip_init; switching devices while sources or tables of the old
+// device are alive is refused by eu_hip_init.
+int init_device(int dev)
+{
+  HIPCHK(hipSetDevice(dev));
+  if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  if (!g.lut) {
+    float lut[257];
+    eu::screen_lut(lut);
+    HIPCHK(hipMalloc((void **)&g.lut, sizeof lut));
+    HIPCHK(hipMemcpy(g.lut, lut, sizeof lut, hipMemcpyHostToDevice));
+  }
+  g.device = dev;
+  return EU_OK;
+}
+
 int ensure_init()
 {
   if (g.device >= 0) return EU_OK;
@@ -92,16 +109,7 @@ int ensure_init()
   int dev = 0;
   const char *lr = getenv("LOCAL_RANK");
   if (lr) dev = atoi(lr) % n;
-  HIPCHK(hipSetDevice(dev));
-  HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  {
-    float lut[257];
-    eu::screen_lut(lut);
-    HIPCHK(hipMalloc((void **)&g.lut, sizeof lut));
-    HIPCHK(hipMemcpy(g.lut, lut, sizeof lut, hipMemcpyHostToDevice));
-  }
-  g.device = dev;
-  return EU_OK;
+  return init_device(dev);
 }
 
 int grow(float **p, size_t *cap, size_t need)
@@ -612,10 +620,11 @@ int eu_hip_init(int device)
   if (n <= 0) return fail(EU_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
   if (device < 0 || device >= n) return fail(EU_ERR_ARGUMENT, "device index out of range");
   if (g.device == device) return EU_OK;
-  HIPCHK(hipSetDevice(device));
-  if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  g.device = device;
-  return EU_OK;
+  // one device per process (one process per GPU): the stream, the LUT, the plan tables and
+  // every resident source live on the device chosen first
+  if (g.device >= 0)
+    return fail(EU_ERR_ARGUMENT, "the library is already initialised on another device");
+  return init_device(device);
 }
 
 int eu_hip_get_extent(int prj, int w, int h, double hfov, double *e)
@@ -802,6 +811,7 @@ static int render_on_device(const eu_target *trg, eu_source *const *srcs, int ns
   size_t fstride = stride_bytes;
   const size_t rows = (size_t)(trg->row_end - trg->row_begin);
   if (screen) {
+    if (!g.lut) return fail(EU_ERR_NO_DEVICE, "sRGB table missing: library not initialised");
     tf.out_format = EU_OUT_FLOAT;
     fstride = (size_t)frame_w(trg) * trg->nchannels * sizeof(float);
     if ((rc = grow(&g.scr, &g.scr_cap, rows * frame_w(trg) * trg->nchannels))) return rc;
@@ -908,7 +918,11 @@ int eu_hip_render_timed(const eu_target *trg, eu_source *const *srcs, int nsrc, 
   if ((rc = check_target(trg))) return rc;
   // one untimed launch builds the plan (stepper tables, derived copies)
   if ((rc = render_on_device(trg, srcs, nsrc, out_dev, out_row_stride_bytes, g.stream))) return rc;
-  hipEvent_t e0, e1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct guard {
+    hipEvent_t &a, &b;
+    ~guard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } events { e0, e1 };
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, g.stream));
@@ -919,8 +933,6 @@ int eu_hip_render_timed(const eu_target *trg, eu_source *const *srcs, int nsrc, 
   float ms = 0.0f;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *mean_ms = ms / iters;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return EU_OK;
 }
 
@@ -936,13 +948,13 @@ int eu_hip_diag_stamps(const eu_target *trg, eu_source *const *srcs, int nsrc, f
   if ((rc = build_params(trg, srcs, nsrc, out_dev, out_row_stride_bytes, &p))) return rc;
   if (p.nch != 3 || p.src.degree != 3 || p.twine) return fail(EU_ERR_ARGUMENT, "diag: NCH 3, degree 3, no twining");
   unsigned long long *d = nullptr;
+  struct guard { unsigned long long *&q; ~guard() { if (q) (void)hipFree(q); } } buf { d };
   HIPCHK(hipMalloc((void **)&d, nwaves * 8 * sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(d, 0, nwaves * 8 * sizeof(unsigned long long), g.stream));
   for (int i = 0; i < 3; i++)
     if (eu_launch_diag(&p, d, g.stream)) return fail(EU_ERR_NO_DEVICE, "diag launch failed");
   HIPCHK(hipStreamSynchronize(g.stream));
   HIPCHK(hipMemcpy(host_stamps, d, nwaves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  (void)hipFree(d);
   return EU_OK;
 }
 
@@ -952,12 +964,12 @@ int eu_hip_selftest_math(unsigned long long seed, int blocks, int iters, unsigne
   int rc;
   if ((rc = ensure_init())) return rc;
   unsigned long long *d = nullptr;
+  struct guard { unsigned long long *&q; ~guard() { if (q) (void)hipFree(q); } } buf { d };
   HIPCHK(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), g.stream));
   if (eu_launch_selftest(seed, blocks, iters, d, g.stream)) return fail(EU_ERR_NO_DEVICE, "selftest launch failed");
   HIPCHK(hipStreamSynchronize(g.stream));
   HIPCHK(hipMemcpy(bad4, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  (void)hipFree(d);
   return EU_OK;
 }
 

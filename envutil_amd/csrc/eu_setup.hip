@@ -674,8 +674,14 @@ extern "C" int eu_launch_to_screen(const float *in, long long in_stride, unsigne
                                    void *stream)
 {
   if (w <= 0 || rows <= 0) return 0;
-  dim3 grid((unsigned)((w + 255) / 256), (unsigned)rows);
-  hipLaunchKernelGGL(to_screen_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, out,
-                     out_stride, w, nch, lut);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  // rows sit in grid.y (at most 65535 per launch): taller frames go in slabs
+  for (int r0 = 0; r0 < rows; r0 += 65535) {
+    const int n = rows - r0 < 65535 ? rows - r0 : 65535;
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(to_screen_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                       in + (long long)r0 * in_stride, in_stride, out + (long long)r0 * out_stride,
+                       out_stride, w, nch, lut);
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
+  return 0;
 }

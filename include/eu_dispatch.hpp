@@ -116,6 +116,8 @@ inline arguments args;            // the reference's global (envutil_basic.h:705
 
 struct dispatch_base
 {
+  // envutil_dispatch.h:55-57; there is no highway target here: 0, named for the GPU
+  std::size_t hwy_target = 0;
   std::string hwy_target_name = "gfx950", hwy_target_str = "HIP/CDNA4";
   virtual int payload(int nchannels, int ninputs, projection_t projection) const = 0;
   virtual ~dispatch_base() {}
