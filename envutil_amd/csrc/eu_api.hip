@@ -12,11 +12,16 @@
 #include <new>
 #include "eu_device.h"
 #include "eu_setup_math.h"
+#include "eu_math2.h"
 
 extern "C" int eu_launch_render(const eu_render_params *p, void *stream);
 extern "C" int eu_launch_diag(const eu_render_params *p, unsigned long long *stamps_dev, void *stream);
 extern "C" int eu_launch_render_multi(const void *p, int degree, void *stream);
 extern "C" int eu_launch_render2(const eu_render_params *p, void *stream);
+extern "C" int eu_launch_render4(const eu_render_params *p, const float *h_row, size_t h_row_floats,
+                                 unsigned long long plan_gen, void *stream);
+extern "C" size_t eu_render4_worklist_ints(size_t ntiles);
+extern "C" size_t eu_render4_worklist_header_ints(void);
 extern "C" int eu_launch_to_screen(const float *in, long long in_stride, unsigned *out,
                                    long long out_stride, int w, int rows, int nch, const float *lut,
                                    void *stream);
@@ -60,9 +65,11 @@ struct context {
   std::vector<float> h_col, h_row;
   std::vector<unsigned char> seg_flags;
   bool seg_valid = false, seg_mixed = false;
+  unsigned long long plan_gen = 0;                // bumped whenever the stepper tables change
   unsigned long long launches = 0;                // render kernel launches so far
   eu_src_dev seg_sd;
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
+  int *wl = nullptr; size_t wl_cap = 0;           // eu_render4.hip work list (count, done, tile ids)
   // the tables of the last target stay valid while (target geometry,
   // orientation, taps) repeat: streaming / tethered jobs re-render the same
   // target many times (envutil_main.cc:1948-1982)
@@ -249,7 +256,11 @@ int new_source(const eu_facet *fct, int spline_degree, int bc0, int bc1, int sup
     s->bc[0] = bc0; s->bc[1] = bc1;
   }
   s->nfloats = (size_t)s->geom.shape[0] * s->geom.shape[1] * s->nch;
-  hipError_t e = hipMalloc((void **)&s->dev, s->nfloats * sizeof(float));
+  // slack behind the container: the LDS-staging kernel (eu_render4.hip) fetches whole
+  // 64-texel instructions, up to 3 rows and 63 texels past a tile's box (never evaluated)
+  const size_t slack = (size_t)4 * s->geom.shape[0] * s->nch + 64 * 4;
+  hipError_t e = hipMalloc((void **)&s->dev, (s->nfloats + slack) * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(s->dev + s->nfloats, 0, slack * sizeof(float));
   if (e != hipSuccess) { delete s; return fail(EU_ERR_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
   fill_src_dev(s);
   if (is_cube(fct->projection)) {
@@ -375,6 +386,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     g.h_col.swap(tb.col);
     g.h_row.swap(tb.row);
     g.seg_valid = false;
+    g.plan_gen++;
   }
   memset(p, 0, sizeof *p);
   p->width = frame_w(t); p->height = frame_h(t);
@@ -535,6 +547,33 @@ int launch_render(const eu_render_params *p, void *st)
 {
   static const int force_v1 = [] { const char *e = getenv("EU_HIP_KERNEL"); return e && e[0] == '1'; }();
   static const bool hybrid = [] { const char *e = getenv("EU_HIP_HYBRID"); return !(e && e[0] == '0'); }();
+  // The LDS-staging kernel (eu_render4.hip). Measured: it wins where the taps
+  // dominate and the tile boxes are small - cubic / quadratic jobs on cubemap sources (config 3:
+  // 1.13 -> 0.99 ms) - and loses to the direct-gather kernels on lat/lon sources (headline 1.22
+  // vs 1.57 ms: the polar faces' boxes do not fit, the equatorial faces tie) and on bilinear
+  // jobs. EU_HIP_R4: 0 never, 1 wherever it applies (tests, A/B runs); read on every call.
+  const char *r4env = getenv("EU_HIP_R4");
+  const int r4mode = r4env ? atoi(r4env) : -1;
+  const bool use_r4 = r4mode == 1 || (r4mode != 0 && is_cube(p->src.prj) && p->src.degree >= 2);
+  if (!force_v1 && use_r4) {
+    // work list of the staged kernel (eu_render4.hip: chunk counters of the persistent kernel,
+    // lists of the tiles left to the direct-gather kernel that follows it on the same stream)
+    const size_t ntiles = (size_t)((p->width + 15) / 16) * (size_t)((p->row_end - p->row_begin + 7) / 8);
+    const size_t need = eu_render4_worklist_ints(ntiles);
+    if (g.wl_cap < need) {
+      if (g.wl) (void)hipFree(g.wl);
+      g.wl = nullptr; g.wl_cap = 0;
+      if (hipMalloc((void **)&g.wl, need * sizeof(int)) != hipSuccess) return -1;
+      if (hipMemsetAsync(g.wl, 0, eu_render4_worklist_header_ints() * sizeof(int), (hipStream_t)st) != hipSuccess) return -1;
+      g.wl_cap = need;
+    }
+    eu_render_params q = *p;
+    q.wl = g.wl;
+    g.launches += 2;
+    const int rc = eu_launch_render4(&q, g.h_row.data(), g.h_row.size(), g.plan_gen, st);
+    if (rc <= 0) return rc;
+    g.launches -= 2;
+  }
   if (!force_v1) {
     // worth it for cubic / quadratic jobs whose rows fall into a few long runs: every run
     // is a launch of its own (a rank's share of a band-interleaved split has many short

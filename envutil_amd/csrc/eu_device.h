@@ -83,6 +83,8 @@ struct eu_render_params {
   // interleaved row bands (multi-GPU tiling, eu_target.band_*): local row yl of this
   // call is frame row eu_frame_row(yl, ...); band_count <= 1: identity
   int band_shift, band_count, band_index;
+  int *wl;                   // eu_render4.hip: chunk counters of the persistent kernel and the lists of
+                             // the tiles left to the direct-gather kernel (layout: EU4_WL_*)
   int layout;                // packed kernel: 0 by environment (default row strips), 1 row strips,
                              // 2 32x16 tiles with direct gathers (eu_render2.hip)
   eu_src_dev src;

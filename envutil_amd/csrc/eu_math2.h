@@ -200,14 +200,19 @@ EU_D2 eu_f2 eu_atan2f_2_xpos(eu_f2 y, eu_f2 x)
 EU_D2 void eu_atan_tab_entry(int idx, float *e)
 {
   // idx = clamp((bits >> 18) - 0xfb7, 0, 80); boundaries 0x3ee00000, 0x3f300000,
-  // 0x3f980000, 0x401c0000 >> 18 = 0xfb8, 0xfcc, 0xfe6, 0x1007
-  int id = idx == 0 ? -1 : idx <= 20 ? 0 : idx <= 46 ? 1 : idx <= 79 ? 2 : 3;
-  const float A[5] = { 1.0f, 2.0f, 1.0f, 1.0f, 0.0f }, B[5] = { 0.0f, -1.0f, -1.0f, -1.5f, -1.0f };
-  const float Cc[5] = { 0.0f, 1.0f, 1.0f, 1.5f, 1.0f }, D[5] = { 1.0f, 2.0f, 1.0f, 1.0f, 0.0f };
-  const float HI[5] = { 0.0f, 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
-  const float LO[5] = { 0.0f, 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
-  int k = id + 1;
-  e[0] = A[k]; e[1] = B[k]; e[2] = Cc[k]; e[3] = D[k]; e[4] = HI[k]; e[5] = LO[k]; e[6] = 0.0f; e[7] = 0.0f;
+  // 0x3f980000, 0x401c0000 >> 18 = 0xfb8, 0xfcc, 0xfe6, 0x1007.
+  // Selects on literals, not indexed constant arrays: a kernel prologue fills the table
+  // without a trip to memory.
+  const int k = idx == 0 ? 0 : idx <= 20 ? 1 : idx <= 46 ? 2 : idx <= 79 ? 3 : 4;
+#define EU_TAB5(v0, v1, v2, v3, v4) (k == 0 ? (v0) : k == 1 ? (v1) : k == 2 ? (v2) : k == 3 ? (v3) : (v4))
+  e[0] = EU_TAB5(1.0f, 2.0f, 1.0f, 1.0f, 0.0f);
+  e[1] = EU_TAB5(0.0f, -1.0f, -1.0f, -1.5f, -1.0f);
+  e[2] = EU_TAB5(0.0f, 1.0f, 1.0f, 1.5f, 1.0f);
+  e[3] = EU_TAB5(1.0f, 2.0f, 1.0f, 1.0f, 0.0f);
+  e[4] = EU_TAB5(0.0f, 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f);
+  e[5] = EU_TAB5(0.0f, 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f);
+  e[6] = 0.0f; e[7] = 0.0f;
+#undef EU_TAB5
 }
 
 EU_D2 eu_f2 eu_atanf_pos2_tab(eu_f2 t, const float *tab)
@@ -265,6 +270,48 @@ EU_D2 eu_f2 eu_atan2f_2_tab(eu_f2 y, eu_f2 x, const float *tab, int x_positive)
     if (!ok.y) r.y = eu_atan2f(y.y, x.y);
   }
   return r;
+}
+
+
+// ---------------------------------------------------------------------------
+// Fast-path-only forms for kernels that hand the rare lanes to another kernel
+// (eu_render4.hip): no scalar fallback, no branch; `ok` is cleared for lanes whose
+// operands are outside the range the FMA sequences are exact for - the caller must
+// not use those lanes' results.
+// ---------------------------------------------------------------------------
+EU_D2 eu_f2 eu_atan2f_2_tab_ok(eu_f2 y, eu_f2 x, const float *tab, int x_positive, eu_i2 &ok)
+{
+  const eu_u2 hx = eu_bits2(x), hy = eu_bits2(y);
+  const eu_u2 ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+  const eu_i2 okx = ((x_positive ? hx : ix) - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 oky = (iy - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  ok = ok & okx & oky;
+  eu_f2 q = eu_div2_safe(y, x);
+  eu_f2 z = eu_atanf_pos2_tab(eu_abs2(q), tab);
+  if (x_positive) return eu_float2(eu_bits2(z) ^ (hy & 0x80000000u));
+  const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const eu_i2 xneg = (eu_i2)(hx >> 31) != 0, yneg = (eu_i2)(hy >> 31) != 0;
+  eu_f2 zl = z - pi_lo;
+  eu_f2 rpos = eu_float2(eu_bits2(z) ^ (hy & 0x80000000u));
+  eu_f2 rneg = eu_sel2(yneg, zl - pi, pi - zl);
+  return eu_sel2(xneg, rneg, rpos);
+}
+
+EU_D2 eu_f2 eu_div2_ok(eu_f2 n, eu_f2 d, eu_i2 &ok)
+{
+  const eu_u2 in = eu_bits2(n) & 0x7fffffffu, id = eu_bits2(d) & 0x7fffffffu;
+  // d in [2^-40, 2^40]; n zero or in [2^-80, 2^40] (as eu_div2_guarded)
+  const eu_i2 okd = (id - 0x2b800000u) <= (0x53800000u - 0x2b800000u);
+  const eu_i2 okn = (in == 0u) | ((in - 0x17800000u) <= (0x53800000u - 0x17800000u));
+  ok = ok & okd & okn;
+  return eu_div2_safe(n, d);
+}
+
+EU_D2 eu_f2 eu_sqrt2_ok(eu_f2 x, eu_i2 &ok)
+{
+  const eu_u2 ix = eu_bits2(x);
+  ok = ok & ((ix - 0x2b800000u) <= (0x53800000u - 0x2b800000u));
+  return eu_sqrt2_safe(x);
 }
 
 #if defined(__HIPCC__)
