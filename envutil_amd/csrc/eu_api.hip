@@ -18,6 +18,8 @@ extern "C" int eu_launch_render(const eu_render_params *p, void *stream);
 extern "C" int eu_launch_diag(const eu_render_params *p, unsigned long long *stamps_dev, void *stream);
 extern "C" int eu_launch_render_multi(const void *p, int degree, void *stream);
 extern "C" int eu_launch_render2(const eu_render_params *p, void *stream);
+extern "C" int eu_launch_diag_coords(const eu_src_dev *s, const float *rays_dev, long n, int variant,
+                                     float *out_dev, void *stream);
 extern "C" int eu_launch_render4(const eu_render_params *p, const float *h_row, size_t h_row_floats,
                                  unsigned long long plan_gen, void *stream);
 extern "C" size_t eu_render4_worklist_ints(size_t ntiles);
@@ -994,6 +996,27 @@ int eu_hip_diag_stamps(const eu_target *trg, eu_source *const *srcs, int nsrc, f
     if (eu_launch_diag(&p, d, g.stream)) return fail(EU_ERR_NO_DEVICE, "diag launch failed");
   HIPCHK(hipStreamSynchronize(g.stream));
   HIPCHK(hipMemcpy(host_stamps, d, nwaves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return EU_OK;
+}
+
+// DIAGNOSTIC (not in eu_hip.h): the ray -> source coordinate stage of the kernels on
+// caller-supplied rays (n x 3 floats, host): variant 0 eu_source_coordinate, 1 eu_coord2,
+// 2 eu_coord2_ok (eu_diag.hip). out = n x 3 floats: x, y, cube face | 0; a miss is 0, 0, -1
+int eu_hip_diag_source_coordinates(const eu_source *src, const float *rays, long n, int variant, float *out)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if (!src || !rays || !out || n < 0) return fail(EU_ERR_ARGUMENT, "null argument");
+  if (n == 0) return EU_OK;
+  float *d = nullptr;
+  struct guard { float *&q; ~guard() { if (q) (void)hipFree(q); } } buf { d };
+  HIPCHK(hipMalloc((void **)&d, (size_t)n * 6 * sizeof(float)));
+  HIPCHK(hipMemcpy(d, rays, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  const int lrc = eu_launch_diag_coords(&src->sd, d, n, variant, d + (size_t)n * 3, g.stream);
+  if (lrc > 0) return fail(EU_ERR_UNSUPPORTED, "the packed forms cover lat/lon, cubemap and biatan6 sources");
+  if (lrc < 0) return fail(EU_ERR_NO_DEVICE, "diag launch failed");
+  HIPCHK(hipStreamSynchronize(g.stream));
+  HIPCHK(hipMemcpy(out, d + (size_t)n * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
   return EU_OK;
 }
 

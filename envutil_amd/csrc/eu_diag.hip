@@ -2,6 +2,7 @@
 // s_memtime stamps between its phases. Never used by eu_hip_render; its
 // timings are read as SHARES of a wave's lifetime, not as kernel time.
 #include "eu_render_dev.h"
+#include "eu_packed_dev.h"
 
 __device__ __forceinline__ unsigned long long eu_stamp()
 {
@@ -160,5 +161,73 @@ extern "C" int eu_launch_selftest(unsigned long long seed, int blocks, int iters
 {
   hipLaunchKernelGGL(eu_selftest_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seed,
                      iters, bad_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+
+// ---------------------------------------------------------------------------
+// the ray -> source coordinate stage on caller-supplied rays (tests of its edge
+// cases: exact ties and signed zeros in ray_to_cubeface, axis-aligned and
+// denormal rays in the mounts). variant 0: eu_source_coordinate (general kernels),
+// 1: eu_coord2 (packed kernels, rays 2k and 2k + 1 in one thread), 2: eu_coord2_ok
+// (staged kernel: no fallbacks; a lane that needs one reports face -2).
+// out3 = { source x, source y, cube face | 0 }, { 0, 0, -1 } for a miss; the
+// packed forms fold the face into y and report 0.
+// ---------------------------------------------------------------------------
+template <int PRJ>
+__device__ void eu_diag_coord_packed(const eu_src_dev &s, const float *rays, long n, long k,
+                                     const float *atab, bool only_ok, float *out3)
+{
+  const long ia = 2 * k, ib = ia + 1 < n ? ia + 1 : ia;
+  eu_ray2 r;
+  r.x = (eu_f2){ rays[3 * ia], rays[3 * ib] };
+  r.y = (eu_f2){ rays[3 * ia + 1], rays[3 * ib + 1] };
+  r.z = (eu_f2){ rays[3 * ia + 2], rays[3 * ib + 2] };
+  eu_f2 sx, sy;
+  eu_i2 hit, ok = { -1, -1 };
+  if (only_ok) hit = eu_coord2_ok<PRJ>(s, r, sx, sy, atab, ok);
+  else hit = eu_coord2<PRJ>(s, r, sx, sy, atab);
+  for (int h = 0; h < 2; h++) {
+    const long i = h ? ib : ia;
+    if (h && ib == ia) break;
+    const bool good = h ? ok.y != 0 : ok.x != 0, hh = h ? hit.y != 0 : hit.x != 0;
+    out3[3 * i] = hh ? (h ? sx.y : sx.x) : 0.0f;
+    out3[3 * i + 1] = hh ? (h ? sy.y : sy.x) : 0.0f;
+    out3[3 * i + 2] = !good ? -2.0f : hh ? 0.0f : -1.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void eu_diag_coord_kernel(const eu_src_dev s, const float *rays,
+                                                            long n, int variant, float *out3)
+{
+  __shared__ __attribute__((aligned(16))) float atab[EU_ATAN_TAB_FLOATS];
+  if (threadIdx.x < EU_ATAN_TAB_ENTRIES) eu_atan_tab_entry(threadIdx.x, atab + 8 * threadIdx.x);
+  __syncthreads();
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  if (variant == 0) {
+    if (k >= n) return;
+    float sx, sy;
+    int face;
+    const bool hit = eu_source_coordinate(s, rays[3 * k], rays[3 * k + 1], rays[3 * k + 2], sx, sy, face);
+    out3[3 * k] = hit ? sx : 0.0f;
+    out3[3 * k + 1] = hit ? sy : 0.0f;
+    out3[3 * k + 2] = hit ? (float)face : -1.0f;
+    return;
+  }
+  if (2 * k >= n) return;
+  switch (s.prj) {
+    case EU_SPHERICAL: eu_diag_coord_packed<EU_SPHERICAL>(s, rays, n, k, atab, variant == 2, out3); break;
+    case EU_CUBEMAP: eu_diag_coord_packed<EU_CUBEMAP>(s, rays, n, k, atab, variant == 2, out3); break;
+    case EU_BIATAN6: eu_diag_coord_packed<EU_BIATAN6>(s, rays, n, k, atab, variant == 2, out3); break;
+  }
+}
+
+extern "C" int eu_launch_diag_coords(const eu_src_dev *s, const float *rays_dev, long n, int variant,
+                                     float *out_dev, void *stream)
+{
+  if (n <= 0) return 0;
+  if (variant != 0 && s->prj != EU_SPHERICAL && s->prj != EU_CUBEMAP && s->prj != EU_BIATAN6) return 1;
+  hipLaunchKernelGGL(eu_diag_coord_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, *s, rays_dev, n, variant, out_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -1272,11 +1272,11 @@ static void ray_to_planar(int projection, const float *ray, float *crd)
 static void planar_lens(const euo_source *src, float *crd);
 static int mount_mask(const mount_t *m, const float *ray);
 
-/* returns the hit mask; px gets nch floats */
-static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
+/* the coordinate half of mount_t::eval: crd3 = { source x, source y, cube face | 0 }; returns
+ * the hit mask (crd3 = { 0, 0, -1 } for a miss) */
+static int mount_coordinate(const mount_t *m, const float *ray, float *crd3)
 {
   const euo_source *src = m->src;
-  int nch = src->spl.nch;
   if (src->projection == EUO_CUBEMAP || src->projection == EUO_BIATAN6) {
     int face;
     float inf[2], pick[2];
@@ -1293,8 +1293,7 @@ static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
     pick[1] += (float)(face * src->section_px);
     pick[0] -= .5f;
     pick[1] -= .5f;
-    if (dbg) { dbg[0] = pick[0]; dbg[1] = pick[1]; dbg[2] = (float)face; }
-    ev_eval(&m->ev, pick[0], pick[1], px);
+    crd3[0] = pick[0]; crd3[1] = pick[1]; crd3[2] = (float)face;
     return 1;
   }
   float crd[2] = { 0.0f, 0.0f };
@@ -1305,8 +1304,7 @@ static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
           && crd[1] >= m->wexf[2] && crd[1] <= m->wexf[3];
   if (src->projection == EUO_RECTILINEAR) mask = mask && (ray[2] > 0.0f);
   if (!mask) {
-    for (int c = 0; c < nch; c++) px[c] = 0.0f;
-    if (dbg) { dbg[0] = dbg[1] = 0.0f; dbg[2] = -1.0f; }
+    crd3[0] = crd3[1] = 0.0f; crd3[2] = -1.0f;
     return 0;
   }
   /* md_to_spline, environment.h:988-1006 */
@@ -1318,10 +1316,23 @@ static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
   ic1 /= (float)(m->tex[3] - m->tex[2]);
   ic1 *= (float)src->height;
   ic1 -= .5f;
-  float s0 = ic0 - (float)src->window_x_offset;
-  float s1 = ic1 - (float)src->window_y_offset;
-  if (dbg) { dbg[0] = s0; dbg[1] = s1; dbg[2] = 0.0f; }
-  ev_eval(&m->ev, s0, s1, px);
+  crd3[0] = ic0 - (float)src->window_x_offset;
+  crd3[1] = ic1 - (float)src->window_y_offset;
+  crd3[2] = 0.0f;
+  return 1;
+}
+
+/* returns the hit mask; px gets nch floats */
+static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
+{
+  float crd3[3];
+  const int mask = mount_coordinate(m, ray, crd3);
+  if (dbg) { dbg[0] = crd3[0]; dbg[1] = crd3[1]; dbg[2] = crd3[2]; }
+  if (!mask) {
+    for (int c = 0; c < m->src->spl.nch; c++) px[c] = 0.0f;
+    return 0;
+  }
+  ev_eval(&m->ev, crd3[0], crd3[1], px);
   return 1;
 }
 
@@ -1372,6 +1383,27 @@ static void env_eval(const mount_t *m, const float *ray, int out_n, float *px, f
   }
 }
 
+/* lcp<float>::eval (lens_correction.h:224-235 on eu_polynomial::function, :93-105):
+ * coefficients {a, b, c, 1 - (a + b + c)} formed in float from the facet's doubles, the sum
+ * runs from the constant term up with `power *= x` behind every term. Pinned against the
+ * reference's own lcp (oracle/ref_zimt.cc: ref_lcp_factor; tests/golden). */
+static float lens_factor(double da, double db, double dc, float x)
+{
+  float a = (float)da, b = (float)db, c = (float)dc;
+  float d = 1.0f - (a + b + c);
+  float sum = 0.0f, power = 1.0f;
+  sum += d * power; power *= x;
+  sum += c * power; power *= x;
+  sum += b * power; power *= x;
+  sum += a * power; power *= x;
+  return sum;
+}
+
+void euo_lens_factor(double a, double b, double c, const float *x, long n, float *out)
+{
+  for (long i = 0; i < n; i++) out[i] = lens_factor(a, b, c, x[i]);
+}
+
 /* lens polynomial + shift + shear, PTO forward direction
  * (environment.h:254-284; lens_correction.h:93-105, :224-235). The flags and
  * the scale s come from process_geometry (envutil_basic.h:499-521). */
@@ -1386,17 +1418,10 @@ static void planar_lens(const euo_source *src, float *crd)
   int has_shear = (src->shear_g != 0.0 || src->shear_t != 0.0);
   float o0 = crd[0], o1 = crd[1];
   if (has_lcp) {
-    /* lcp<float>: coefficients {a, b, c, 1 - (a + b + c)} in float */
-    float a = (float)src->a, b = (float)src->b, c = (float)src->c;
-    float d = 1.0f - (a + b + c);
     float sqn = crd[0] * crd[0];
     sqn += crd[1] * crd[1];
     float x = sqrtf(sqn) / (float)sd;
-    float sum = 0.0f, power = 1.0f;
-    sum += d * power; power *= x;
-    sum += c * power; power *= x;
-    sum += b * power; power *= x;
-    sum += a * power; power *= x;
+    float sum = lens_factor(src->a, src->b, src->c, x);
     o0 *= sum; o1 *= sum;
   }
   if (has_shift) { o0 += (float)src->h; o1 += (float)src->v; }
@@ -1684,6 +1709,16 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
   }
   free(taps); free(sy); free(st);
   return 0;
+}
+
+/* mount_t::get_coordinate / cubemap_view_t pickup for caller-supplied rays (tests of the edge
+ * cases of ray_to_cubeface and the mounts: exact ties, signed zeros, axis-aligned rays):
+ * out3 = { source x, source y, cube face | 0 } and { 0, 0, -1 } for a miss */
+void euo_source_coordinates(const euo_source *src, const float *rays, long n, float *out3)
+{
+  mount_t mnt;
+  mount_init(&mnt, src);
+  for (long i = 0; i < n; i++) mount_coordinate(&mnt, rays + 3 * i, out3 + 3 * i);
 }
 
 int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,

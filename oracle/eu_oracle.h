@@ -147,6 +147,8 @@ int    euo_render(const euo_job *job, const euo_source *src, int nsrc,
 
 /* geometry functors, double precision, for the reference's own property
  * tests (geometry.cc:283-420) */
+void   euo_lens_factor(double a, double b, double c, const float *x, long n, float *out);
+void   euo_source_coordinates(const euo_source *src, const float *rays, long n, float *out3);
 void   euo_prj_to_ray_d(int projection, const double *in2, double *out3);
 void   euo_ray_to_prj_d(int projection, const double *in3, double *out2);
 

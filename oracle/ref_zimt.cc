@@ -13,7 +13,9 @@
 // segment 512, compiled with -ffp-contract=off: the pinned oracle definition
 // of SURVEY.md §8(c).
 //
-// envutil's own headers (geometry.h, stepper.h, environment.h, cubemap.h,
+//   * the PTO lens polynomial lcp            (lens_correction.h: it includes nothing
+//     but zimt/eval.h, so it compiles in place)
+// envutil's other headers (geometry.h, stepper.h, environment.h, cubemap.h,
 // twining.h) cannot be compiled here: every one of them reaches
 // envutil_basic.h:198-200, which includes OpenImageIO (absent from the image).
 // Those stages are restated from the source text and are NOT pinned by this
@@ -26,6 +28,7 @@
 #include "zimt/bspline.h"
 #include "zimt/prefilter.h"
 #include "zimt/eval.h"
+#include "lens_correction.h"
 
 namespace {
 
@@ -262,3 +265,18 @@ void ref_lut_eval(const float *knots, long size, const float *in, long n, float 
 }
 
 }  // extern "C"
+
+// lcp<float, L>::eval (lens_correction.h:224-235), constructed the way pto_planar does
+// (environment.h:247-252: the facet's double a, b, c narrow at the call), evaluated on
+// zimt's 16-lane vectors as the pixel pipeline does; n is padded internally
+extern "C" void ref_lcp_factor(double a, double b, double c, const float *x, long n, float *out)
+{
+  project::lcp<float, L> f(a, b, c, 0.0);
+  typedef zimt::simdized_type<float, L> f_v;
+  for (long i0 = 0; i0 < n; i0 += (long)L) {
+    f_v v(0.0f), r;
+    for (std::size_t l = 0; l < L && i0 + (long)l < n; l++) v[l] = x[i0 + l];
+    f.eval(v, r);
+    for (std::size_t l = 0; l < L && i0 + (long)l < n; l++) out[i0 + l] = r[l];
+  }
+}

@@ -187,3 +187,26 @@ def cubemap_build(faces, spline_degree, prefilter_degree, face_fov=np.pi / 2,
     lib().euo_cubemap_build(C.byref(m), ptr(faces), nch, spline_degree,
                             prefilter_degree, ptr(ir))
     return m, ir
+
+
+def lens_factor(a, b, c, x):
+    """the oracle's lcp<float>::eval (oracle/eu_oracle.c: lens_factor)"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    f = lib().euo_lens_factor
+    f.restype = None
+    f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_long, C.c_void_p]
+    f(a, b, c, x.ctypes.data, len(x), out.ctypes.data)
+    return out
+
+
+def source_coordinates(src, rays):
+    """mount_t::get_coordinate / cubemap pickup for caller-supplied rays: (n, 3) -> (n, 3) of
+    {source x, source y, cube face | 0}, {0, 0, -1} for a miss"""
+    rays = np.ascontiguousarray(rays, np.float32)
+    out = np.zeros_like(rays)
+    f = lib().euo_source_coordinates
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+    f(C.byref(src), rays.ctypes.data, len(rays), out.ctypes.data)
+    return out

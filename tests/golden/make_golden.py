@@ -106,6 +106,18 @@ def main():
     out["lut_knots"] = knots
     out["lut_in"] = vin
     out["lut_out"] = refz.lut_eval(knots, vin)
+    # the PTO lens polynomial (lens_correction.h compiles in place: it includes only
+    # zimt/eval.h): radial factor for r / s in [0, 2.5], several coefficient sets incl. the
+    # one of BASELINE config 5; its own file
+    lx = np.concatenate([np.linspace(0.0, 2.5, 2000).astype(np.float32),
+                         rng.random(2000, dtype=np.float32) * np.float32(1.5),
+                         np.array([0.0, 1.0, 0.5, 1e-20, 3.0], np.float32)])
+    sets = np.array([[0.01, -0.03, 0.02], [0.0, 0.0, 0.05], [-0.12, 0.3, -0.21],
+                     [1e-3, 0.0, 0.0], [0.25, 0.25, 0.25]], np.float64)
+    lcp = {"lcp_x": lx, "lcp_abc": sets,
+           "lcp_out": np.stack([refz.lcp_factor(*abc, lx) for abc in sets])}
+    np.savez_compressed(os.path.join(HERE, "lcp_golden.npz"), **lcp)
+    print("wrote", os.path.join(HERE, "lcp_golden.npz"))
     np.savez_compressed(os.path.join(HERE, "zimt_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "zimt_golden.npz"),
           os.path.getsize(os.path.join(HERE, "zimt_golden.npz")), "bytes")

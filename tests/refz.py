@@ -121,3 +121,14 @@ def lut_eval(knots, vin):
     f.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
     f(knots.ctypes.data, len(knots), vin.ctypes.data, len(vin), out.ctypes.data)
     return out
+
+
+def lcp_factor(a, b, c, x):
+    """project::lcp<float, 16>(a, b, c).eval on 16-lane vectors (lens_correction.h:224-235)"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    f = lib().ref_lcp_factor
+    f.restype = None
+    f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_long, C.c_void_p]
+    f(a, b, c, x.ctypes.data, len(x), out.ctypes.data)
+    return out

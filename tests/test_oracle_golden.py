@@ -117,3 +117,12 @@ def test_to_screen_packing():
     assert ((w3 >> 16) & 0xFF) in (126, 127, 128)      # sRGB(0.214) ~ 0.5
     w4 = ts(4)
     assert (w4 >> 24) in (186, 187, 188) and (w4 & 0xFFFFFF) == (w3 & 0xFFFFFF)
+
+
+def test_lens_polynomial_against_reference_fixture():
+    """oracle's lcp<float>::eval (planar_lens' radial factor, config 5) against outputs of the
+    reference's own lens_correction.h (compiled in place, tests/golden/make_golden.py)"""
+    G2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lcp_golden.npz"))
+    for abc, ref in zip(G2["lcp_abc"], G2["lcp_out"]):
+        got = euo.lens_factor(*abc, G2["lcp_x"])
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all(), abc

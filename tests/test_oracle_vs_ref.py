@@ -62,3 +62,15 @@ def test_weights_and_poles():
         if d >= 2:
             assert (euo.poles(d).astype(np.float32)
                     == refz.poles(d).astype(np.float32)).all()
+
+
+def test_lens_polynomial_sweep():
+    """lcp<float>::eval of the oracle against the reference's lens_correction.h, compiled in
+    place: random coefficient triples, radii over [0, 4] and all floats of a few binades"""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.random(20000, dtype=np.float32) * np.float32(4.0),
+                        np.arange(0x3f000000, 0x3f000000 + 50000, dtype=np.uint32).view(np.float32),
+                        np.arange(0x3f800000 - 25000, 0x3f800000 + 25000, dtype=np.uint32).view(np.float32)])
+    for _ in range(40):
+        a, b, c = (rng.uniform(-0.4, 0.4) for _ in range(3))
+        assert (bits(euo.lens_factor(a, b, c, x)) == bits(refz.lcp_factor(a, b, c, x))).all(), (a, b, c)
