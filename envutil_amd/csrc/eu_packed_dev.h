@@ -5,6 +5,10 @@
 #ifndef EU_PACKED_DEV_H
 #define EU_PACKED_DEV_H
 
+#ifndef EU_CUBEFACE_BALLOT
+#define EU_CUBEFACE_BALLOT 0   // eu_coord2_ok: wavefront ballot on the cube-face dominance class (measured: DESIGN.md 5)
+#endif
+
 #include "eu_render_dev.h"
 #include "eu_math2.h"
 
@@ -326,14 +330,32 @@ __device__ __forceinline__ eu_i2 eu_coord2_ok(const eu_src_dev &s, const eu_ray2
     const eu_f2 ax = eu_abs2(r.x), ay = eu_abs2(r.y), az = eu_abs2(r.z);
     const eu_i2 m1 = ax >= ay, m2 = ax >= az, m3 = ay >= az;
     const eu_i2 domx = m1 & m2, domz = (~m2) & (~m3);
-    const eu_f2 num0 = eu_sel2(domx, -r.z, eu_sel2(domz, r.x, -r.x));
-    const eu_f2 den0 = eu_sel2(domx, r.x, eu_sel2(domz, r.z, ay));
-    const eu_f2 num1 = eu_sel2(domx, r.y, eu_sel2(domz, r.y, r.z));
-    const eu_f2 den1 = eu_sel2(domx, ax, eu_sel2(domz, az, r.y));
+    eu_f2 num0, den0, num1, den1;
+    eu_i2 face;
+#if EU_CUBEFACE_BALLOT
+    // wavefront ballot on the dominance class (the GPU form of the reference's any_of(dom)
+    // early-outs, geometry.h:1224-1287): a wave whose 128 pixels agree - all but the waves on a
+    // cube edge - takes that class's operands without the select ladder
+    const unsigned long long bx = __ballot(domx.x && domx.y), bz = __ballot(domz.x && domz.y);
+    const unsigned long long by = __ballot(!(domx.x | domx.y | domz.x | domz.y)), all = __ballot(1);
+    if (bx == all) {
+      num0 = -r.z; den0 = r.x; num1 = r.y; den1 = ax; face = eu_sel2i(r.x < 0.0f, 0, 1);
+    } else if (bz == all) {
+      num0 = r.x; den0 = r.z; num1 = r.y; den1 = az; face = eu_sel2i(r.z < 0.0f, 5, 4);
+    } else if (by == all) {
+      num0 = -r.x; den0 = ay; num1 = r.z; den1 = r.y; face = eu_sel2i(r.y < 0.0f, 2, 3);
+    } else
+#endif
+    {
+      num0 = eu_sel2(domx, -r.z, eu_sel2(domz, r.x, -r.x));
+      den0 = eu_sel2(domx, r.x, eu_sel2(domz, r.z, ay));
+      num1 = eu_sel2(domx, r.y, eu_sel2(domz, r.y, r.z));
+      den1 = eu_sel2(domx, ax, eu_sel2(domz, az, r.y));
+      const eu_i2 fx = eu_sel2i(r.x < 0.0f, 0, 1), fz = eu_sel2i(r.z < 0.0f, 5, 4),
+                  fy = eu_sel2i(r.y < 0.0f, 2, 3);
+      face = eu_sel2i(domx, fx, eu_sel2i(domz, fz, fy));
+    }
     eu_f2 in0 = eu_div2_ok(num0, den0, ok), in1 = eu_div2_ok(num1, den1, ok);
-    const eu_i2 fx = eu_sel2i(r.x < 0.0f, 0, 1), fz = eu_sel2i(r.z < 0.0f, 5, 4),
-                fy = eu_sel2i(r.y < 0.0f, 2, 3);
-    const eu_i2 face = eu_sel2i(domx, fx, eu_sel2i(domz, fz, fy));
     if constexpr (PRJ == EU_BIATAN6) {
       const float k = (float)(4.0 / 3.14159265358979323846);
       eu_f2 a0 = eu_atanf_pos2_tab(eu_abs2(in0), atab), a1 = eu_atanf_pos2_tab(eu_abs2(in1), atab);
