@@ -151,29 +151,63 @@ __device__ float iacc(const iir_dev &f, const L &c, int M, int k)
   }
 }
 
-// The recursions are sequential by definition (and stay so: same operations in
-// the same order as recursive.h), but their LOADS are not: a line is walked in
-// blocks of EU_IIR_BLOCK samples that are read into registers first, so that a
-// thread has that many loads in flight instead of one per dependent step.
-#define EU_IIR_BLOCK 16
+// The recursions are sequential by definition (and stay so: same operations in the same order
+// as recursive.h), but their LOADS are not. A launch has one thread per line - 24 576 lines for
+// the 16K x 8K RGB source, 1.5 wavefronts per CU - so what a sweep achieves is (bytes a thread
+// keeps in flight) / (memory latency): a line is walked in blocks of EU_IIR_BLOCK samples, and
+// the loads of block k + 1 are issued before the dependent chain of block k runs (two register
+// buffers). 16 samples, one buffer: 0.9 TB/s (4.1 + 3.0 ms for the two passes of that source);
+// profiles/r02_prefilter.txt has the numbers for this form.
+#ifndef EU_IIR_BLOCK
+#define EU_IIR_BLOCK 64
+#endif
+
+template <class L>
+__device__ __forceinline__ void iir_load(const L &x, int n, int dir, float *v)
+{
+#pragma unroll
+  for (int i = 0; i < EU_IIR_BLOCK; i++) v[i] = x.get(n + dir * i);
+}
+template <class L>
+__device__ __forceinline__ void iir_store(const L &x, int n, int dir, const float *v)
+{
+#pragma unroll
+  for (int i = 0; i < EU_IIR_BLOCK; i++) x.put(n + dir * i, v[i]);
+}
 
 // forward: X = gain * x[n] + p * X (gain == 1 and the product skipped for k > 0)
 template <bool GAIN, class L>
 __device__ __forceinline__ float causal_pass(const L &x, int M, float g, float p, float X)
 {
   int n = 1;
-  for (; n + EU_IIR_BLOCK <= M; n += EU_IIR_BLOCK) {
-    float v[EU_IIR_BLOCK];
+  if (n + EU_IIR_BLOCK <= M) {
+    float a[EU_IIR_BLOCK], b[EU_IIR_BLOCK];
+    iir_load(x, n, 1, a);
+    for (;;) {
+      // block at n is in a; request the one behind it into b, then run a's chain
+      const bool more = n + 2 * EU_IIR_BLOCK <= M;
+      if (more) iir_load(x, n + EU_IIR_BLOCK, 1, b);
 #pragma unroll
-    for (int i = 0; i < EU_IIR_BLOCK; i++) v[i] = x.get(n + i);
+      for (int i = 0; i < EU_IIR_BLOCK; i++) {
+        if constexpr (GAIN) X = g * a[i] + p * X;
+        else X = a[i] + p * X;
+        a[i] = X;
+      }
+      iir_store(x, n, 1, a);
+      n += EU_IIR_BLOCK;
+      if (!more) break;
+      const bool more2 = n + 2 * EU_IIR_BLOCK <= M;
+      if (more2) iir_load(x, n + EU_IIR_BLOCK, 1, a);
 #pragma unroll
-    for (int i = 0; i < EU_IIR_BLOCK; i++) {
-      if constexpr (GAIN) X = g * v[i] + p * X;
-      else X = v[i] + p * X;
-      v[i] = X;
+      for (int i = 0; i < EU_IIR_BLOCK; i++) {
+        if constexpr (GAIN) X = g * b[i] + p * X;
+        else X = b[i] + p * X;
+        b[i] = X;
+      }
+      iir_store(x, n, 1, b);
+      n += EU_IIR_BLOCK;
+      if (!more2) break;
     }
-#pragma unroll
-    for (int i = 0; i < EU_IIR_BLOCK; i++) x.put(n + i, v[i]);
   }
   for (; n < M; n++) {
     if constexpr (GAIN) X = g * x.get(n) + p * X;
@@ -188,14 +222,25 @@ template <class L>
 __device__ __forceinline__ void anticausal_pass(const L &x, int M, float p, float X)
 {
   int n = M - 2;
-  for (; n - (EU_IIR_BLOCK - 1) >= 0; n -= EU_IIR_BLOCK) {
-    float v[EU_IIR_BLOCK];
+  if (n - (EU_IIR_BLOCK - 1) >= 0) {
+    float a[EU_IIR_BLOCK], b[EU_IIR_BLOCK];
+    iir_load(x, n, -1, a);
+    for (;;) {
+      const bool more = n - (2 * EU_IIR_BLOCK - 1) >= 0;
+      if (more) iir_load(x, n - EU_IIR_BLOCK, -1, b);
 #pragma unroll
-    for (int i = 0; i < EU_IIR_BLOCK; i++) v[i] = x.get(n - i);
+      for (int i = 0; i < EU_IIR_BLOCK; i++) { X = p * (X - a[i]); a[i] = X; }
+      iir_store(x, n, -1, a);
+      n -= EU_IIR_BLOCK;
+      if (!more) break;
+      const bool more2 = n - (2 * EU_IIR_BLOCK - 1) >= 0;
+      if (more2) iir_load(x, n - EU_IIR_BLOCK, -1, a);
 #pragma unroll
-    for (int i = 0; i < EU_IIR_BLOCK; i++) { X = p * (X - v[i]); v[i] = X; }
-#pragma unroll
-    for (int i = 0; i < EU_IIR_BLOCK; i++) x.put(n - i, v[i]);
+      for (int i = 0; i < EU_IIR_BLOCK; i++) { X = p * (X - b[i]); b[i] = X; }
+      iir_store(x, n, -1, b);
+      n -= EU_IIR_BLOCK;
+      if (!more2) break;
+    }
   }
   for (; n >= 0; n--) { X = p * (X - x.get(n)); x.put(n, X); }
 }
@@ -224,7 +269,7 @@ __device__ void solve_line(const iir_dev &f, const L &x, int M)
 }
 
 // lines: nl x nch threads; line i channel c starts at base + i*line_stride + c
-__global__ void filter_lines_kernel(iir_dev f, float *base, long long nl, int nch,
+__global__ __launch_bounds__(64) void filter_lines_kernel(iir_dev f, float *base, long long nl, int nch,
                                     long long line_stride, int len, long long es)
 {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,7 +280,7 @@ __global__ void filter_lines_kernel(iir_dev f, float *base, long long nl, int nc
   solve_line(f, ln, len);
 }
 
-__global__ void filter_stacked_kernel(iir_dev f, float *core, long long half, int nch,
+__global__ __launch_bounds__(64) void filter_stacked_kernel(iir_dev f, float *core, long long half, int nch,
                                       long long row_es, int H)
 {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
