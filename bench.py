@@ -100,8 +100,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}: launch with "
+                         "torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available() or ea.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     # EU_BENCH_REHEARSE=1: the N-rank logic on however many GPUs there are (all ranks may
@@ -190,6 +190,8 @@ def main():
     tgt = args.target(nch, r0, r1, 0, band)
 
     def step():
+        if r1 <= r0:
+            return          # a rank without rows (more ranks than row units) only joins the collectives
         rc = ea.lib().eu_hip_render(C.byref(tgt), srcs, nsrcs, C.c_void_p(out.data_ptr()),
                                     tw * nch * 4, 1, None)
         if rc:
@@ -246,18 +248,37 @@ def main():
         del frame
 
     # ---- kernel-only time with HIP events on the kernel's stream ------------
-    kernel_ms = ea.render_timed(args, sources, out.data_ptr(), max(a.steps, 5), nch, r0, r1, band)
+    kernel_ms = ea.render_timed(args, sources, out.data_ptr(), max(a.steps, 5), nch, r0, r1, band) if r1 > r0 else 0.0
 
     # ---- the boundary with HOST buffers (never `value`): pixels in, pixels out ----
     # load = H2D of the source + prefilter/brace on the device; render_to_host =
     # kernel + D2H of the frame into pageable memory (second call: pages touched)
     host_ms = None
+    pcie = None
     if world == 1 and nsrcs == 1 and not a.no_cpu_baseline:
         hbuf = np.empty((r1 - r0, tw, nch), np.float32)
         ea.render(args, src, nch, r0, r1, out=hbuf)
         th0 = time.perf_counter()
         ea.render(args, src, nch, r0, r1, out=hbuf)
         host_ms = 1e3 * (time.perf_counter() - th0)
+        # what the link gives for the same bytes: a plain device -> PINNED host copy, and the
+        # same into the pageable buffer the call above was given
+        try:
+            pin = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            pin.copy_(out); torch.cuda.synchronize()
+            tp0 = time.perf_counter(); pin.copy_(out); torch.cuda.synchronize()
+            t_pin = time.perf_counter() - tp0
+            hb = torch.from_numpy(hbuf)
+            hb.copy_(out); torch.cuda.synchronize()
+            tp0 = time.perf_counter(); hb.copy_(out); torch.cuda.synchronize()
+            t_page = time.perf_counter() - tp0
+            nbytes = out.numel() * 4
+            pcie = {"frame_bytes": nbytes, "pinned_copy_ms": round(1e3 * t_pin, 2),
+                    "pinned_GBps": round(nbytes / t_pin / 1e9, 1),
+                    "pageable_copy_ms": round(1e3 * t_page, 2)}
+            del pin, hb
+        except Exception as e:      # no pinned memory on this box: report the render only
+            pcie = {"error": str(e)[:80]}
         del hbuf
 
     probe = None
@@ -284,20 +305,34 @@ def main():
     else:
         n_src = sw * sh
     n_src *= nsrcs
-    src_share = n_src if world == 1 else n_src / world
-    alg_bytes = 4.0 * nch * (src_share + npix_rank)
+    # per rank: the WHOLE source (a rank's rows of a cubemap or spherical target span all
+    # longitudes, band-interleaved shares all latitudes too) + its own output rows
+    alg_bytes = 4.0 * nch * (n_src + npix_rank)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
-    traffic = None
+    # HBM traffic is a RECORD, not measured in this run: PMC counters need rocprofv3 passes of
+    # their own (tools/gpu_prof.sh); profiles/traffic.json holds the last ones, with their round
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf) and world == 1:
         try:
             rec = json.load(open(tf))
-            if rec.get("workload") == a.workload:
-                traffic = rec.get("hbm_bytes_per_launch")
+            w_ = rec.get("workloads", {}).get(a.workload)
+            if w_:
+                traffic = w_.get("hbm_bytes_per_step")
+                traffic_source = f"profiles/traffic.json, {rec.get('round')}: {w_.get('kernels')}"
         except Exception:
             traffic = None
 
+    if nsrcs > 1:
+        kernel_name = "eu_render_multi_kernel"
+    elif sprj in (5, 6) and degree in (2, 3) and nch in (3, 4) and not twine and os.environ.get("EU_HIP_R4", "") != "0":
+        kernel_name = "eu_render4s_kernel (per-wave LDS staging of the footprint) + eu_render4d_kernel (its work list)"
+    elif sprj in (0, 5, 6) and degree in (1, 2, 3):
+        kernel_name = ("eu_render2_kernel (packed two-pixel; big cubic lat/lon jobs: + eu_render3_kernel on the row "
+                       "runs where source rows run across, launch-level layout choice)")
+    else:
+        kernel_name = "eu_render_kernel"
     result = {
         "metric": "Mpix/s reprojected (16K lat/lon->cubemap, b-spline-3)",
         "value": round(value, 1),
@@ -318,14 +353,16 @@ def main():
                        f"contiguous strips of equal estimated cost over {world} ranks" if ranges is not None
                        else f"bands of {BAND_ROWS} rows, round-robin over {world} ranks"),
                    "gather_ms_untimed": None if gather_ms is None else round(gather_ms, 3),
+                   "value_incl_gather": None if gather_ms is None else round(npix_total / (ms_per_step + gather_ms) / 1e3, 1),
                    "setup_s": round(t_setup, 2),
                    "host_boundary": {"source_load_s": round(t_load, 3),
                                      "render_to_host_ms": None if host_ms is None else round(host_ms, 1),
-                                     "note": "pageable host memory over PCIe; not part of value"}},
+                                     "d2h_reference": pcie,
+                                     "note": "render_to_host = kernel + D2H of the frame into the caller's pageable buffer; not part of value"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic,
-                     "kernel": "eu_render_multi_kernel" if nsrcs > 1 else ("eu_render2_kernel (packed two-pixel; big cubic lat/lon jobs: + eu_render3_kernel on the row runs where source rows run across, launch-level layout choice)" if (sprj in (0, 5, 6) and degree in (1, 2, 3)) else "eu_render_kernel"), "kernel_ms": round(kernel_ms, 4),
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                      "launches_per_step": launches_per_step,
                      "algorithmic_bytes": alg_bytes},
     }

@@ -23,6 +23,19 @@ def broadcast_source(dist, tensor, src_rank=0):
     return tensor
 
 
+def _exchange(dist, ops):
+    """post all point-to-point operations of a gather as ONE batch (RCCL runs them as a group:
+    every sender's link is busy at once) and wait; backends without batching take them one by one"""
+    if not ops:
+        return
+    try:
+        reqs = dist.batch_isend_irecv([dist.P2POp(fn, t, peer) for fn, t, peer in ops])
+    except (RuntimeError, AttributeError, NotImplementedError):
+        reqs = [fn(t, peer) for fn, t, peer in ops]
+    for q in reqs:
+        q.wait()
+
+
 def gather_strips(dist, strip, height, width, nch, rank, world_size, dst=0, align=1):
     """collect every rank's (rows, width, nch) strip on `dst`; returns the full
     frame there, None elsewhere. Strips may differ in height: point-to-point
@@ -34,18 +47,17 @@ def gather_strips(dist, strip, height, width, nch, rank, world_size, dst=0, alig
         frame = torch.empty((height, width, nch), dtype=strip.dtype, device=strip.device)
         r0, r1 = row_partition(height, world_size, rank, align)
         frame[r0:r1].copy_(strip)
-        reqs = []
+        ops = []
         for r in range(world_size):
             if r == dst:
                 continue
             q0, q1 = row_partition(height, world_size, r, align)
             if q1 > q0:
-                reqs.append(dist.irecv(frame[q0:q1], src=r))
-        for q in reqs:
-            q.wait()
+                ops.append((dist.irecv, frame[q0:q1], r))
+        _exchange(dist, ops)
         return frame
     if strip.shape[0] > 0:
-        dist.send(strip.contiguous(), dst=dst)
+        _exchange(dist, [(dist.isend, strip.contiguous(), dst)])
     return None
 
 
@@ -76,21 +88,20 @@ def gather_bands(dist, strip, height, width, nch, rank, world_size, band_rows, d
     if rank == dst:
         frame = torch.empty((height, width, nch), dtype=strip.dtype, device=strip.device)
         frame[band_frame_rows(height, band_rows, world_size, rank).to(strip.device)] = strip
-        bufs, reqs = {}, []
+        bufs, ops = {}, []
         for r in range(world_size):
             if r == dst:
                 continue
             n = band_local_rows(height, band_rows, world_size, r)
             if n:
                 bufs[r] = torch.empty((n, width, nch), dtype=strip.dtype, device=strip.device)
-                reqs.append(dist.irecv(bufs[r], src=r))
-        for q in reqs:
-            q.wait()
+                ops.append((dist.irecv, bufs[r], r))
+        _exchange(dist, ops)
         for r, b in bufs.items():
             frame[band_frame_rows(height, band_rows, world_size, r).to(strip.device)] = b
         return frame
     if strip.shape[0] > 0:
-        dist.send(strip.contiguous(), dst=dst)
+        _exchange(dist, [(dist.isend, strip.contiguous(), dst)])
     return None
 
 
@@ -112,11 +123,17 @@ def cost_partition(height, world_size, seg_rows, flags, flag_cost=2.0, align=64)
         if f:
             w[k * seg_rows:(k + 1) * seg_rows] = flag_cost
     cum = np.concatenate([[0.0], np.cumsum(w)])
+    if height < world_size * align:
+        # too small to give every rank an aligned strip by cost: plain equal strips (a rank may
+        # still come out empty when there are fewer rows than ranks; callers skip its render)
+        return [row_partition(height, world_size, r) for r in range(world_size)]
     bounds = [0]
     for r in range(1, world_size):
         y = int(np.searchsorted(cum, cum[-1] * r / world_size))
         y = int(round(y / align)) * align
-        bounds.append(min(max(y, bounds[-1]), height))
+        # every rank keeps at least `align` rows, also the ones behind this boundary
+        y = min(max(y, bounds[-1] + align), height - (world_size - r) * align)
+        bounds.append(y)
     bounds.append(height)
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
@@ -131,14 +148,13 @@ def gather_ranges(dist, strip, ranges, height, width, nch, rank, world_size, dst
         frame = torch.empty((height, width, nch), dtype=strip.dtype, device=strip.device)
         r0, r1 = ranges[rank]
         frame[r0:r1].copy_(strip)
-        reqs = []
+        ops = []
         for r in range(world_size):
             q0, q1 = ranges[r]
             if r != dst and q1 > q0:
-                reqs.append(dist.irecv(frame[q0:q1], src=r))
-        for q in reqs:
-            q.wait()
+                ops.append((dist.irecv, frame[q0:q1], r))
+        _exchange(dist, ops)
         return frame
     if strip.shape[0] > 0:
-        dist.send(strip.contiguous(), dst=dst)
+        _exchange(dist, [(dist.isend, strip.contiguous(), dst)])
     return None
