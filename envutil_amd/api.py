@@ -120,6 +120,7 @@ def lib():
     L.eu_hip_source_device_ptr.argtypes = [vp, vp, vp]
     L.eu_hip_source_download.argtypes = [vp, vp, C.c_size_t]
     L.eu_hip_source_info.argtypes = [vp, vp, vp]
+    L.eu_hip_source_update_facet.argtypes = [vp, vp]
     L.eu_hip_source_release.argtypes = [vp]
     L.eu_hip_render.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
     L.eu_hip_render_timed.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
@@ -253,6 +254,12 @@ class Source:
         _check(lib().eu_hip_source_alloc(C.byref(cf), spline_degree, support_min, tile_size,
                                          C.byref(h)))
         return cls(h, fct)
+
+    def update_facet(self, fct):
+        """the facet's geometry changed (orientation, hfov, lens, brighten): rebuild the
+        evaluator / mount parameters, keep the resident coefficients"""
+        _check(lib().eu_hip_source_update_facet(self.handle, C.byref(fct.c_struct())))
+        self.fct = fct
 
     def device_ptr(self):
         p = C.c_void_p()

@@ -71,6 +71,7 @@ struct context {
   unsigned long long launches = 0;                // render kernel launches so far
   eu_src_dev seg_sd;
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
+  hipStream_t last_user = nullptr;                // caller's stream of the last render (eu_hip_sync waits on it too)
   hipStream_t copy = nullptr;                     // D2H of a host-output frame, chunk by chunk
   hipEvent_t chunk_done[4] = { nullptr, nullptr, nullptr, nullptr };
   int *wl = nullptr; size_t wl_cap = 0;           // eu_render4.hip work list (count, done, tile ids)
@@ -370,6 +371,8 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     eu::stepper_tables tb;
     if (!eu::build_stepper_tables(*t, basis, twine, twine, tb))
       return fail(EU_ERR_UNSUPPORTED, "no stepper for this target projection");
+    // a kernel of the previous job may still read the tables on the caller's stream
+    if (g.last_user) HIPCHK(hipStreamSynchronize(g.last_user));
     if ((rc = grow(&g.col, &g.col_cap, tb.col.size()))) return rc;
     if ((rc = grow(&g.row, &g.row_cap, tb.row.size()))) return rc;
     HIPCHK(hipMemcpyAsync(g.col, tb.col.data(), tb.col.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
@@ -450,6 +453,7 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
     if (twine) memcpy(q, t->taps, 3 * sizeof(float) * (size_t)t->ntaps);
   }
   int rc;
+  if (g.last_user) HIPCHK(hipStreamSynchronize(g.last_user));   // g.msrc and the tables are rewritten below
   if (key != g.mplan_key) {
     eu::mat3 r_cam = eu::make_r3(t->roll, t->pitch, t->yaw, false);
     std::vector<float> rows;
@@ -808,6 +812,27 @@ int eu_hip_source_alloc(const eu_facet *fct, int spline_degree, int support_min,
   return new_source(fct, spline_degree, bc0, bc1, support_min, tile_size, out);
 }
 
+int eu_hip_source_update_facet(eu_source *src, const eu_facet *fct)
+{
+  int rc;
+  if (!src) return fail(EU_ERR_HANDLE, "null source");
+  if ((rc = check_facet(fct))) return rc;
+  const eu_facet &o = src->fct;
+  // what the resident container was built from stays as it is
+  if (fct->projection != o.projection || fct->nchannels != o.nchannels || fct->width != o.width ||
+      fct->height != o.height || fct->window_width != o.window_width || fct->window_height != o.window_height)
+    return fail(EU_ERR_ARGUMENT, "the facet's image (projection, size, channels) differs from the resident one");
+  if (is_cube(o.projection) && fct->hfov != o.hfov)
+    return fail(EU_ERR_ARGUMENT, "a cubemap's field of view is part of its resident image");
+  const eu_src_dev keep = src->sd;
+  src->fct = *fct;
+  fill_src_dev(src);
+  if (is_cube(o.projection)) {
+    src->sd.refc_md = keep.refc_md; src->sd.model_to_px = keep.model_to_px; src->sd.section_px = keep.section_px;
+  }
+  return EU_OK;
+}
+
 int eu_hip_source_device_ptr(const eu_source *src, void **dev_ptr, size_t *nfloats)
 {
   if (!src) return fail(EU_ERR_HANDLE, "null source");
@@ -893,6 +918,7 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   if (out_row_stride_bytes % sizeof(float)) return fail(EU_ERR_ARGUMENT, "row stride must be a multiple of 4 bytes");
   if (nsrc > 1 && trg->stage) return fail(EU_ERR_ARGUMENT, "stage outputs exist for single-facet jobs only");
   hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+  g.last_user = stream ? (hipStream_t)stream : nullptr;
   if (out_on_device) return render_on_device(trg, srcs, nsrc, out, out_row_stride_bytes, st);
   const size_t rows = (size_t)(trg->row_end - trg->row_begin);
   if (!rows) return EU_OK;
@@ -968,6 +994,7 @@ int eu_hip_sync(void)
 {
   if (g.device < 0) return EU_OK;
   HIPCHK(hipStreamSynchronize(g.stream));
+  if (g.last_user) HIPCHK(hipStreamSynchronize(g.last_user));
   return EU_OK;
 }
 

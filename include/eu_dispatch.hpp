@@ -156,6 +156,12 @@ struct hip_dispatch : public dispatch_base
                                     args.support_min, args.tile_size, &s);
         if (rc != EU_OK) return rc;
         it = resident.emplace(fct.asset_key, s).first;
+      } else {
+        // the asset is resident; its facet_spec may have changed since (orientation, hfov,
+        // lens, brighten): the reference reads it fresh on every job
+        eu_facet e = to_eu(fct);
+        int rc = eu_hip_source_update_facet(it->second, &e);
+        if (rc != EU_OK) return rc;
       }
       srcs.push_back(it->second);
     }

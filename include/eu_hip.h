@@ -15,6 +15,14 @@
  *
  * All functions return 0 on success or a negative eu_status code; none of them
  * aborts. eu_hip_last_error() gives the text for the calling thread.
+ *
+ * Threading: like the reference's payload (called on the main thread, global `args`), the
+ * library is NOT re-entrant: one host thread at a time, one device per process (the first
+ * eu_hip_init or the first call fixes it). A caller-supplied stream orders the KERNELS of a
+ * render; the stepper tables of a job are uploaded synchronously before its launch, and the
+ * library waits for the previous job's stream before it rewrites them, so jobs on different
+ * streams never race on the library's own buffers. eu_hip_sync() waits for the library's
+ * stream and for the stream of the last render.
  */
 #ifndef EU_HIP_H
 #define EU_HIP_H
@@ -175,6 +183,12 @@ int  eu_hip_source_adopt(const eu_facet *fct, const float *container,
  * after which the source stays resident like any other. */
 int  eu_hip_source_alloc(const eu_facet *fct, int spline_degree,
                          int support_min, int tile_size, eu_source **out);
+/* The asset_handler caches the b-spline only; the facet's geometry (yaw / pitch / roll,
+ * hfov, window offsets, lens a/b/c/h/v, shear, brighten, step) is read fresh from facet_spec
+ * on every job (environment.h:84-227). A host that keeps sources resident calls this before a
+ * job whose facet_spec changed: the evaluator and mount parameters are rebuilt from `fct`, the
+ * coefficients stay. The image itself (projection, size, channels) must be the resident one. */
+int  eu_hip_source_update_facet(eu_source *src, const eu_facet *fct);
 int  eu_hip_source_device_ptr(const eu_source *src, void **dev_ptr,
                               size_t *nfloats);
 /* copy the device-resident container back (tests, checkpointing) */

@@ -2,6 +2,7 @@
 CPU oracle on identical inputs. BIT-EXACT (float32 compared as uint32) at every
 stage: rays, source coordinates, pixels, and the device-built coefficients."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -479,3 +480,45 @@ def test_windowed_source_bit_exact(sprj, shfov, window):
                          o2.container, 3, o2.bc[0], o2.bc[1])
     a = ea.arguments(ea.SPHERICAL, 240, 120, 360.0, spline_degree=3)
     assert_bits(ea.render(a, [g, g2], 3), jobs.oracle_render(a, [o, o2]), "windowed facets, synopsis")
+
+
+def test_explicit_init_then_tethered_in_a_fresh_process():
+    """eu_hip_init() as the FIRST call of a process (bench.py, one process per GPU) must set up
+    everything the implicit initialisation does - the sRGB table of the tethered path was once
+    missing behind it - and a second, different device is refused"""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import envutil_amd as ea, euo, jobs
+L = ea.lib()
+assert L.eu_hip_init(0) == 0
+assert L.eu_hip_init(0) == 0
+assert L.eu_hip_init(10 ** 6) != 0
+img = jobs.synth_image(128, 64, 3)
+o = jobs.OracleSource(euo.SPHERICAL, 128, 64, 360.0, img, 1)
+g = ea.Source.adopt(ea.facet_spec(euo.SPHERICAL, 128, 64, 360.0), o.container, 1, o.bc[0], o.bc[1])
+a = ea.arguments(ea.SPHERICAL, 90, 45, 360.0, spline_degree=1, tethered=True)
+got, ref = ea.render(a, g), jobs.oracle_render(a, o)
+assert got.dtype == np.uint32 and (got == ref).all()
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_resident_source_follows_its_facet_spec(latlon):
+    """asset_handler semantics (environment.h:84-227): the coefficients stay resident, the
+    facet's orientation / hfov / brighten / lens are read fresh for every job"""
+    img = jobs.synth_image(128, 128, 3)
+    o0, g = make_pair(euo.FISHEYE, 128, 128, 160.0, img, 1)
+    a = ea.arguments(ea.SPHERICAL, 160, 80, 360.0, spline_degree=1)
+    assert_bits(ea.render(a, g), jobs.oracle_render(a, o0), "as loaded")
+    kw = dict(yaw=40.0, pitch=-15.0, roll=20.0, brighten=1.5, lens=dict(a=0.01, b=-0.03, c=0.02))
+    o1 = jobs.OracleSource(euo.FISHEYE, 128, 128, 150.0, img, 1, **kw)
+    g.update_facet(ea.facet_spec(euo.FISHEYE, 128, 128, 150.0, nchannels=3, **kw))
+    assert_bits(ea.render(a, g), jobs.oracle_render(a, o1), "after the facet changed")
+    with pytest.raises(ea.EuError):
+        g.update_facet(ea.facet_spec(euo.FISHEYE, 64, 64, 150.0, nchannels=3))
