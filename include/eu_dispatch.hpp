@@ -43,6 +43,9 @@ struct facet_base : public extent_type
   double shear_g = 0.0, shear_t = 0.0;
   double s = 0.0, a = 0.0, b = 0.0, c = 0.0, d = 0.0, h = 0.0, v = 0.0;
   bool has_shift = false, has_lcp = false, has_shear = false;
+  // PTO translation and reprojection plane (envutil_basic.h:441-446): parsed by the front
+  // end, rendered by code outside this path (generic_r3 / tf_ex_facet): payload() refuses them
+  double tr_x = 0.0, tr_y = 0.0, tr_z = 0.0, tp_y = 0.0, tp_p = 0.0, tp_r = 0.0;
 
   // facet_base::process_geometry, envutil_basic.h:499-521
   void process_geometry()
@@ -64,8 +67,12 @@ struct facet_spec : public facet_base
 {
   int facet_no = 0;
   int nchannels = 3;
+  std::string filename, projection_str;
   std::string asset_key;          // residency key (environment.h:84-227)
   float brighten = 1.0f;
+  int masked = -1;                // --mask_for (envutil_main.cc:1080-1092)
+  bool has_lens_crop = false, has_pto_mask = false;
+  int crop_x0 = 0, crop_x1 = 0, crop_y0 = 0, crop_y1 = 0;
   const float *pixels = nullptr;  // window_width x window_height x nchannels (cubemaps: 6 faces)
 };
 
@@ -74,6 +81,12 @@ struct arguments : public facet_base
   int spline_degree = 1, prefilter_degree = -1;
   int twine = 0;
   float twine_width = 1.0f, twine_sigma = 0.0f, twine_threshold = 0.0f;
+  float twine_density = 1.0f;
+  int twine_max = 8;
+  bool twine_normalize = false, twine_precise = false;
+  float brighten = 1.0f;
+  std::string output, split, synopsis = "panorama", pto_file, twf_file, projection_str;
+  int solo = -1, single = -1, mask_for = -1;
   std::vector<std::array<float, 3>> twine_spread;
   int support_min = 8, tile_size = 64;
   int nchannels = 3;
@@ -100,10 +113,33 @@ struct arguments : public facet_base
     nfacets = int(facet_spec_v.size());
   }
 
-  // make_spread for an explicitly given --twine (envutil_main.cc:1253-1355, :1585-1590)
+  // arguments::twine_setup, envutil_main.cc:1405-1616: --twine N (N >= 0) is taken as given;
+  // -1 (the command line's default) derives twine and twine_width from the magnification
+  // smallest facet step / target step; then twine_density, then make_spread
+  // (envutil_main.cc:1253-1355). A twf file (tap table from disk) is file I/O: not here.
   void twine_setup()
   {
     twine_spread.clear();
+    if (twine != -1) {
+      if (twine < 0) twine = 0;
+    } else {
+      double smallest_step = 1e300;
+      if (nfacets == 1 || solo > 0) smallest_step = facet_spec_v[size_t(solo < 0 ? 0 : solo)].step;
+      else for (const auto &f : facet_spec_v) smallest_step = f.step < smallest_step ? f.step : smallest_step;
+      const double mag = smallest_step / step;
+      if (mag > 1.0) {
+        if (spline_degree > 1) twine = nfacets > 1 ? 3 : (mag < 2.0 ? 2 : 1);
+        else {
+          twine = int(1.0 + mag) < 5 ? int(1.0 + mag) : 5;
+          twine_width = float(mag);
+        }
+      } else {
+        twine = int(1.0 + 1.0 / mag);
+        if (twine > twine_max) twine = twine_max;
+        twine_width = 1.0f;
+      }
+    }
+    if (twine_density != 1.0f) twine = int(std::round(twine * twine_density));
     if (twine <= 0) return;
     std::vector<float> t(3 * size_t(twine < 2 ? 4 : twine * twine));
     int n = eu_hip_make_spread(twine, twine, twine_width, twine_sigma, twine_threshold, t.data(),
@@ -146,6 +182,13 @@ struct hip_dispatch : public dispatch_base
     if (projection != args.projection) return EU_ERR_ARGUMENT;
     if ((ninputs == 9) != !args.twine_spread.empty()) return EU_ERR_ARGUMENT;
     if (args.tethered ? !args.p_screen_data : !args.p_output) return EU_ERR_ARGUMENT;
+    // outside this path: unstitching, masks, lens crops, translated facets, the
+    // other synopsis modes - the reference's CPU dispatch keeps them
+    if (args.single >= 0 || !args.split.empty() || args.synopsis != "panorama") return EU_ERR_UNSUPPORTED;
+    for (const auto &fct : args.facet_spec_v)
+      if (fct.has_pto_mask || fct.has_lens_crop || fct.masked != -1 || fct.tr_x != 0.0 || fct.tr_y != 0.0 ||
+          fct.tr_z != 0.0 || fct.tp_y != 0.0 || fct.tp_p != 0.0 || fct.tp_r != 0.0)
+        return EU_ERR_UNSUPPORTED;
     std::vector<eu_source *> srcs;
     for (const auto &fct : args.facet_spec_v) {
       auto it = resident.find(fct.asset_key);
