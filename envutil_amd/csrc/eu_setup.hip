@@ -280,14 +280,278 @@ __global__ __launch_bounds__(64) void filter_lines_kernel(iir_dev f, float *base
   solve_line(f, ln, len);
 }
 
-__global__ __launch_bounds__(64) void filter_stacked_kernel(iir_dev f, float *core, long long half, int nch,
-                                      long long row_es, int H)
+__global__ __launch_bounds__(64) void filter_stacked_kernel(iir_dev f, float *core, long long count,
+                                      long long down_off, long long row_es, int H)
 {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= half * nch) return;   // t = x * nch + c
-  stacked_line ln { core + t, core + t + half * nch, row_es, H };
+  if (t >= count) return;   // t = x * nch + c
+  stacked_line ln { core + t, core + t + down_off, row_es, H };
   solve_line(f, ln, 2 * H);
 }
+
+// ---------------------------------------------------------------------------
+// The same sweeps, streamed. The recursions above move every sample with one 4-byte access per
+// lane; in the row direction the 64 lanes of a wavefront then touch 64 different cache lines
+// per instruction (64 cycles of the texture addresser each: 16 384 samples x 4 accesses x 64
+// cycles = 1.7 ms per wavefront is what the row pass of the 16K x 8K source cost), and in the
+// column direction a wavefront has at most 63 such accesses in flight. Here ONE wavefront per
+// workgroup walks its lines in blocks of 64 samples through LDS tiles:
+//   * LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no registers)
+//     requests block b + EU_IIR_AHEAD while block b is worked on,
+//   * the lanes that own a line run the recursion on the tile in place (ds_read / ds_write,
+//     the operations and their order are those of causal_pass / anticausal_pass),
+//   * the tile goes back with 16-byte stores.
+// What remains serial is the recursion itself: 3 VALU + 2 LDS instructions per sample from a
+// single wavefront. Lanes per wavefront are kept LOW (8 rows x nch, 32 columns) so that the
+// 24 576 lines of that source make ~1000 wavefronts, one per SIMD of the chip.
+// vmcnt counts LDS-DMA and stores in issue order; every vector memory instruction inside the
+// block loops is inline asm, so the counts below are exact.
+// ---------------------------------------------------------------------------
+#define EU_IIR_AHEAD 3
+#define EU_IIR_BUFS (EU_IIR_AHEAD + 1)
+
+typedef __attribute__((address_space(3))) float *iir_lptr;
+typedef __attribute__((address_space(3))) void *iir_lvoid;
+typedef float iir_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) iir_f4 *iir_l4ptr;
+
+__device__ __forceinline__ void iir_dma16(unsigned dst, const float *src)
+{
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\t"
+               "s_mov_b32 m0, %1\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dwordx4 %2, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "v"(src) : "memory");
+}
+__device__ __forceinline__ void iir_store16(float *dst, iir_f4 v)
+{
+  // the two wait states a VALU write of the data registers must keep from a store of more than
+  // 8 bytes (the compiler's hazard recogniser does not look into inline asm)
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+}
+template <int N> __device__ __forceinline__ void iir_wait_vm()
+{
+  static_assert(N >= 0 && N <= 63, "vmcnt holds 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// R rows x NCH channels per wavefront; a block is 64 samples = 64*NCH floats of every row.
+// LDS pitch 64*NCH + 4 floats: the chain lanes (row i, channel c) sit at bank 4i + c + NCH*n.
+template <int NCH, int R> struct tile_rows {
+  static constexpr int STRIDE = NCH, PITCH = 64 * NCH + 4, FLOATS = R * PITCH, OPS = R;
+  static_assert(R <= 16 && R * NCH <= 64, "bank pattern / lanes");
+  float *g;          // this lane's 16-byte chunk of row 0, block 0
+  long long ls;      // floats between rows
+  int lane;
+  __device__ bool mover() const { return lane < 16 * NCH; }
+  __device__ int chain_off() const { return (lane / NCH) * PITCH + lane % NCH; }
+  __device__ void request(unsigned lds, int blk) const
+  {
+    if (mover()) {
+      const float *s = g + (long long)blk * (64 * NCH);
+#pragma unroll
+      for (int r = 0; r < R; r++) iir_dma16(lds + r * (PITCH * 4), s + r * ls);
+    }
+  }
+  __device__ void writeback(iir_lptr t, int blk) const
+  {
+    if (mover()) {
+      float *d = g + (long long)blk * (64 * NCH);
+      iir_f4 v[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) v[r] = *(iir_l4ptr)(t + r * PITCH + lane * 4);
+#pragma unroll
+      for (int r = 0; r < R; r++) iir_store16(d + r * ls, v[r]);
+    }
+  }
+};
+
+// L adjacent floats of every row per wavefront (L/4 chunks x 256/L rows per instruction); with
+// STACKED sample n >= H is row 2H-1-n of the other half (stacked_line)
+template <int L, bool STACKED> struct tile_cols {
+  static constexpr int STRIDE = L, FLOATS = 64 * L, OPS = L / 4, RPI = 256 / L;
+  float *up, *down;  // this lane's chunk in row 0
+  long long es; int H;
+  int lane;
+  __device__ int chain_off() const { return lane; }
+  __device__ float *rowptr(int n) const
+  {
+    if (STACKED && n >= H) return down + (long long)(2 * H - 1 - n) * es;
+    return up + (long long)n * es;
+  }
+  __device__ void request(unsigned lds, int blk) const
+  {
+    const int n0 = blk * 64 + lane / (L / 4);
+#pragma unroll
+    for (int q = 0; q < OPS; q++) iir_dma16(lds + q * 1024, rowptr(n0 + q * RPI));
+  }
+  __device__ void writeback(iir_lptr t, int blk) const
+  {
+    const int n0 = blk * 64 + lane / (L / 4);
+    iir_f4 v[OPS];
+#pragma unroll
+    for (int q = 0; q < OPS; q++) v[q] = *(iir_l4ptr)(t + q * 256 + lane * 4);
+#pragma unroll
+    for (int q = 0; q < OPS; q++) iir_store16(rowptr(n0 + q * RPI), v[q]);
+  }
+};
+
+template <class T> __device__ __forceinline__ unsigned iir_buf(unsigned lds0, int b)
+{
+  return lds0 + (unsigned)(b % EU_IIR_BUFS) * (unsigned)(T::FLOATS * 4);
+}
+
+// blocks 0 .. nblk-1 forward; sample 0 becomes X (the initial coefficient)
+template <bool GAIN, class T>
+__device__ __forceinline__ float stream_causal(const T &tl, float *smem, int nblk, bool active,
+                                               float g, float p, float X)
+{
+  const unsigned lds0 = (unsigned)(unsigned long long)(iir_lvoid)smem;
+  for (int b = 0; b < EU_IIR_AHEAD && b < nblk; b++) tl.request(iir_buf<T>(lds0, b), b);
+  for (int b = 0; b < nblk; b++) {
+    if (b + EU_IIR_AHEAD < nblk) {
+      tl.request(iir_buf<T>(lds0, b + EU_IIR_AHEAD), b + EU_IIR_AHEAD);
+      // behind the requests of block b: those of the AHEAD blocks after it and the stores of
+      // the min(b, AHEAD) blocks before it
+      if (b >= EU_IIR_AHEAD) iir_wait_vm<2 * T::OPS * EU_IIR_AHEAD>();
+      else iir_wait_vm<T::OPS * EU_IIR_AHEAD>();
+    } else {
+      iir_wait_vm<0>();
+    }
+    iir_lptr tile = (iir_lptr)smem + (b % EU_IIR_BUFS) * T::FLOATS;
+    if (active) {
+      iir_lptr t = tile + tl.chain_off();
+      float a[64];
+#pragma unroll
+      for (int i = 0; i < 64; i++) a[i] = t[i * T::STRIDE];
+      {
+        float Y;
+        if constexpr (GAIN) Y = g * a[0] + p * X; else Y = a[0] + p * X;
+        X = b == 0 ? X : Y;
+        a[0] = X;
+      }
+#pragma unroll
+      for (int i = 1; i < 64; i++) {
+        if constexpr (GAIN) X = g * a[i] + p * X; else X = a[i] + p * X;
+        a[i] = X;
+      }
+#pragma unroll
+      for (int i = 0; i < 64; i++) t[i * T::STRIDE] = a[i];
+    }
+    tl.writeback(tile, b);
+  }
+  return X;
+}
+
+// blocks nblk-1 .. 0 backward; with `first` sample 64*nblk-1 becomes X (it is the line's last)
+template <class T>
+__device__ __forceinline__ void stream_anticausal(const T &tl, float *smem, int nblk, bool active,
+                                                  float p, float X, bool first)
+{
+  const unsigned lds0 = (unsigned)(unsigned long long)(iir_lvoid)smem;
+  for (int j = 0; j < EU_IIR_AHEAD && j < nblk; j++) tl.request(iir_buf<T>(lds0, j), nblk - 1 - j);
+  for (int j = 0; j < nblk; j++) {
+    const int b = nblk - 1 - j;
+    if (j + EU_IIR_AHEAD < nblk) {
+      tl.request(iir_buf<T>(lds0, j + EU_IIR_AHEAD), b - EU_IIR_AHEAD);
+      if (j >= EU_IIR_AHEAD) iir_wait_vm<2 * T::OPS * EU_IIR_AHEAD>();
+      else iir_wait_vm<T::OPS * EU_IIR_AHEAD>();
+    } else {
+      iir_wait_vm<0>();
+    }
+    iir_lptr tile = (iir_lptr)smem + (j % EU_IIR_BUFS) * T::FLOATS;
+    if (active) {
+      iir_lptr t = tile + tl.chain_off();
+      float a[64];
+#pragma unroll
+      for (int i = 63; i >= 0; i--) a[i] = t[i * T::STRIDE];
+      {
+        float Y = p * (X - a[63]);
+        X = (first && j == 0) ? X : Y;
+        a[63] = X;
+      }
+#pragma unroll
+      for (int i = 62; i >= 0; i--) { X = p * (X - a[i]); a[i] = X; }
+#pragma unroll
+      for (int i = 63; i >= 0; i--) t[i * T::STRIDE] = a[i];
+    }
+    tl.writeback(tile, b);
+  }
+}
+
+// solve_line with the block part of every sweep streamed; M >= 64
+template <class Ln, class T>
+__device__ void solve_line_stream(const iir_dev &f, const Ln &x, const T &tl, int M, bool active, float *smem)
+{
+  const int nblk = M / 64, n1 = nblk * 64;
+  const float g = f.gain;
+  for (int k = 0; k < f.npoles; k++) {
+    const float p = f.pole[k];
+    float X = 0.0f;
+    if (active) { X = icc(f, x, M, k); if (k == 0) X = g * X; }
+    if (k == 0) X = stream_causal<true>(tl, smem, nblk, active, g, p, X);
+    else X = stream_causal<false>(tl, smem, nblk, active, 1.0f, p, X);
+    if (active)
+      for (int n = n1; n < M; n++) {
+        if (k == 0) X = g * x.get(n) + p * X; else X = x.get(n) + p * X;
+        x.put(n, X);
+      }
+    iir_wait_vm<0>();
+    const bool tail = n1 < M;
+    if (active) {
+      X = iacc(f, x, M, k);
+      if (tail) {
+        x.put(M - 1, X);
+        for (int n = M - 2; n >= n1; n--) { X = p * (X - x.get(n)); x.put(n, X); }
+      }
+    }
+    stream_anticausal(tl, smem, nblk, active, p, X, !tail);
+    iir_wait_vm<0>();
+  }
+}
+
+template <int NCH, int R>
+__global__ __launch_bounds__(64) void filter_rows_stream_kernel(iir_dev f, float *base, long long line_stride, int len)
+{
+  __shared__ __attribute__((aligned(16))) float smem[EU_IIR_BUFS * tile_rows<NCH, R>::FLOATS];
+  const int lane = threadIdx.x;
+  float *rows = base + (long long)blockIdx.x * R * line_stride;
+  tile_rows<NCH, R> tl { rows + lane * 4, line_stride, lane };
+  const bool active = lane < R * NCH;
+  const int li = active ? lane / NCH : 0, c = lane % NCH;
+  strided_line ln { rows + li * line_stride + c, NCH };
+  solve_line_stream(f, ln, tl, len, active, smem);
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void filter_cols_stream_kernel(iir_dev f, float *base, long long es, int len)
+{
+  __shared__ __attribute__((aligned(16))) float smem[EU_IIR_BUFS * tile_cols<L, false>::FLOATS];
+  const int lane = threadIdx.x;
+  float *cols = base + (long long)blockIdx.x * L;
+  tile_cols<L, false> tl { cols + (lane % (L / 4)) * 4, nullptr, es, 0, lane };
+  const bool active = lane < L;
+  strided_line ln { cols + (active ? lane : 0), es };
+  solve_line_stream(f, ln, tl, len, active, smem);
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void filter_stacked_stream_kernel(iir_dev f, float *core, long long down_off,
+                                                                  long long row_es, int H)
+{
+  __shared__ __attribute__((aligned(16))) float smem[EU_IIR_BUFS * tile_cols<L, true>::FLOATS];
+  const int lane = threadIdx.x;
+  float *cols = core + (long long)blockIdx.x * L;
+  float *mine = cols + (lane % (L / 4)) * 4;
+  tile_cols<L, true> tl { mine, mine + down_off, row_es, H, lane };
+  const bool active = lane < L;
+  float *own = cols + (active ? lane : 0);
+  stacked_line ln { own, own + down_off, row_es, H };
+  solve_line_stream(f, ln, tl, 2 * H, active, smem);
+}
+
 
 // zimt/brace.h:134-330 for one axis; slices span the whole container
 __device__ __forceinline__ long long brace_source(int bc, long long lsz, long long m,
@@ -540,6 +804,64 @@ __global__ void fill_tie_kernel(float *ir, int nch, int face, int stripe, long l
 
 inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// EU_HIP_IIR_STREAM=0: the one-thread-per-line kernels only (the form the streamed ones are
+// checked against on the device, tests/test_gpu_prefilter_stream.py)
+int iir_stream_on()   // bit 0: rows, bit 1: columns
+{
+  const char *e = getenv("EU_HIP_IIR_STREAM");
+  return e ? atoi(e) : 3;
+}
+
+constexpr int IIR_ROWS = 8, IIR_COLS = 32;
+
+// nl rows of len samples x nch channels (es = nch), rows line_stride floats apart
+void launch_filter_rows(const iir_dev &f, float *base, long long nl, int nch, long long line_stride,
+                        int len, hipStream_t st)
+{
+  long long done = 0;
+  if ((iir_stream_on() & 1) && len >= 64 && nch >= 1 && nch <= 4 && nl >= IIR_ROWS) {
+    const unsigned groups = (unsigned)(nl / IIR_ROWS);
+    switch (nch) {
+      case 1: hipLaunchKernelGGL((filter_rows_stream_kernel<1, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len); break;
+      case 2: hipLaunchKernelGGL((filter_rows_stream_kernel<2, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len); break;
+      case 3: hipLaunchKernelGGL((filter_rows_stream_kernel<3, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len); break;
+      default: hipLaunchKernelGGL((filter_rows_stream_kernel<4, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len);
+    }
+    done = (long long)groups * IIR_ROWS;
+  }
+  if (done < nl)
+    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for((nl - done) * nch, 64)), dim3(64), 0, st, f,
+                       base + done * line_stride, nl - done, nch, line_stride, len, (long long)nch);
+}
+
+// nfloats adjacent columns (every float of a row is a line of its own), rows es floats apart
+void launch_filter_cols(const iir_dev &f, float *base, long long nfloats, long long es, int len, hipStream_t st)
+{
+  long long done = 0;
+  if ((iir_stream_on() & 2) && len >= 64 && nfloats >= IIR_COLS) {
+    const unsigned groups = (unsigned)(nfloats / IIR_COLS);
+    hipLaunchKernelGGL((filter_cols_stream_kernel<IIR_COLS>), dim3(groups), dim3(64), 0, st, f, base, es, len);
+    done = (long long)groups * IIR_COLS;
+  }
+  if (done < nfloats)
+    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(nfloats - done, 64)), dim3(64), 0, st, f,
+                       base + done, nfloats - done, 1, 1LL, len, es);
+}
+
+// environment.h:395-447: column t top -> bottom, then column t + down_off bottom -> top
+void launch_filter_stacked(const iir_dev &f, float *core, long long nfloats, long long row_es, int H, hipStream_t st)
+{
+  long long done = 0;
+  if ((iir_stream_on() & 2) && 2 * H >= 64 && nfloats >= IIR_COLS) {
+    const unsigned groups = (unsigned)(nfloats / IIR_COLS);
+    hipLaunchKernelGGL((filter_stacked_stream_kernel<IIR_COLS>), dim3(groups), dim3(64), 0, st, f, core, nfloats, row_es, H);
+    done = (long long)groups * IIR_COLS;
+  }
+  if (done < nfloats)
+    hipLaunchKernelGGL(filter_stacked_kernel, dim3(blocks_for(nfloats - done, 64)), dim3(64), 0, st, f,
+                       core + done, nfloats - done, nfloats, row_es, H);
+}
+
 }  // namespace
 
 extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int nch, int bc0,
@@ -548,16 +870,13 @@ extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int 
   hipStream_t st = (hipStream_t)stream;
   const long long W = g->core[0], H = g->core[1], SX = g->shape[0], SY = g->shape[1];
   float *core = container + ((long long)g->left[1] * SX + g->left[0]) * nch;
-  const int bs = 64;
   if (spherical) {
     // environment.h:356-522
     if (degree > 1) {
       iir_dev f = make_iir(EU_BC_PERIODIC, degree, 0.0001L, W);
-      hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(H * nch, bs)), dim3(bs), 0, st,
-                         f, core, H, nch, SX * nch, (int)W, (long long)nch);
+      launch_filter_rows(f, core, H, nch, SX * nch, (int)W, st);
       iir_dev f2 = make_iir(EU_BC_PERIODIC, degree, 0.0001L, 2 * H);
-      hipLaunchKernelGGL(filter_stacked_kernel, dim3(blocks_for((W / 2) * nch, bs)), dim3(bs), 0, st,
-                         f2, core, W / 2, nch, SX * nch, (int)H);
+      launch_filter_stacked(f2, core, (W / 2) * nch, SX * nch, (int)H, st);
     }
     long long n = (g->left[1] + g->right[1]) * W * nch;
     if (n > 0)
@@ -572,11 +891,9 @@ extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int 
   // bspline::prefilter, zimt/bspline.h:1017-1041 + prefilter.h:133-190
   if (degree > 1) {
     iir_dev f0 = make_iir(bc0, degree, (long double)FLT_EPSILON, W);
-    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(H * nch, bs)), dim3(bs), 0, st, f0,
-                       core, H, nch, SX * nch, (int)W, (long long)nch);
+    launch_filter_rows(f0, core, H, nch, SX * nch, (int)W, st);
     iir_dev f1 = make_iir(bc1, degree, (long double)FLT_EPSILON, H);
-    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(W * nch, bs)), dim3(bs), 0, st, f1,
-                       core, W, nch, (long long)nch, (int)H, SX * nch);
+    launch_filter_cols(f1, core, W * nch, SX * nch, (int)H, st);
   }
   long long nb0 = (g->left[0] + g->right[0]) * SY * nch;
   if (nb0 > 0)
@@ -618,12 +935,9 @@ extern "C" int eu_launch_cubemap_build(const float *faces, float *ir, int nch, l
   if (prefilter_degree > 1) {
     // cubemap.h:921-946: per section, NATURAL x NATURAL, default tolerance
     iir_dev f = make_iir(EU_BC_NATURAL, prefilter_degree, (long double)FLT_EPSILON, S);
-    hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(6LL * S * nch, 64)), dim3(64), 0, st, f,
-                       ir, 6LL * S, nch, (long long)S * nch, (int)S, (long long)nch);
+    launch_filter_rows(f, ir, 6LL * S, nch, (long long)S * nch, (int)S, st);
     for (int face = 0; face < 6; face++)
-      hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for((long long)S * nch, 64)), dim3(64), 0,
-                         st, f, ir + (long long)face * S * S * nch, (long long)S, nch,
-                         (long long)nch, (int)S, (long long)S * nch);
+      launch_filter_cols(f, ir + (long long)face * S * S * nch, (long long)S * nch, (long long)S * nch, (int)S, st);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
