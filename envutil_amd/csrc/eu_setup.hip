@@ -307,7 +307,15 @@ __global__ __launch_bounds__(64) void filter_stacked_kernel(iir_dev f, float *co
 // vmcnt counts LDS-DMA and stores in issue order; every vector memory instruction inside the
 // block loops is inline asm, so the counts below are exact.
 // ---------------------------------------------------------------------------
+#ifndef EU_IIR_AHEAD
 #define EU_IIR_AHEAD 3
+#endif
+#ifdef EU_IIR_EXPERIMENT   // timing experiments only (results are wrong): 1 no recursion, 2 no requests, 4 no write-back
+__device__ int iir_exp;
+#define IIR_EXP(bit) (iir_exp & (bit))
+#else
+#define IIR_EXP(bit) 0
+#endif
 #define EU_IIR_BUFS (EU_IIR_AHEAD + 1)
 
 typedef __attribute__((address_space(3))) float *iir_lptr;
@@ -349,7 +357,7 @@ template <int NCH, int R> struct tile_rows {
   __device__ int chain_off() const { return (lane / NCH) * PITCH + lane % NCH; }
   __device__ void request(unsigned lds, int blk) const
   {
-    if (mover()) {
+    if (mover() && !IIR_EXP(2)) {
       const float *s = g + (long long)blk * (64 * NCH);
 #pragma unroll
       for (int r = 0; r < R; r++) iir_dma16(lds + r * (PITCH * 4), s + r * ls);
@@ -357,7 +365,7 @@ template <int NCH, int R> struct tile_rows {
   }
   __device__ void writeback(iir_lptr t, int blk) const
   {
-    if (mover()) {
+    if (mover() && !IIR_EXP(4)) {
       float *d = g + (long long)blk * (64 * NCH);
       iir_f4 v[R];
 #pragma unroll
@@ -384,12 +392,14 @@ template <int L, bool STACKED> struct tile_cols {
   __device__ void request(unsigned lds, int blk) const
   {
     const int n0 = blk * 64 + lane / (L / 4);
+    if (IIR_EXP(2)) return;
 #pragma unroll
     for (int q = 0; q < OPS; q++) iir_dma16(lds + q * 1024, rowptr(n0 + q * RPI));
   }
   __device__ void writeback(iir_lptr t, int blk) const
   {
     const int n0 = blk * 64 + lane / (L / 4);
+    if (IIR_EXP(4)) return;
     iir_f4 v[OPS];
 #pragma unroll
     for (int q = 0; q < OPS; q++) v[q] = *(iir_l4ptr)(t + q * 256 + lane * 4);
@@ -398,30 +408,55 @@ template <int L, bool STACKED> struct tile_cols {
   }
 };
 
-template <class T> __device__ __forceinline__ unsigned iir_buf(unsigned lds0, int b)
+// one LDS buffer: the tile and, behind it, the 64 checkpoints of the block (one per lane)
+template <class T> struct iir_bufs {
+  static constexpr int BUF = T::FLOATS + 64;
+  static __device__ __forceinline__ unsigned at(unsigned lds0, int k) { return lds0 + (unsigned)(k % EU_IIR_BUFS) * (unsigned)(BUF * 4); }
+};
+
+__device__ __forceinline__ void iir_dma4(unsigned dst, const float *src)
 {
-  return lds0 + (unsigned)(b % EU_IIR_BUFS) * (unsigned)(T::FLOATS * 4);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\t"
+               "s_mov_b32 m0, %1\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dword %2, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "v"(src) : "memory");
+}
+__device__ __forceinline__ void iir_store4(float *dst, float v)
+{
+  asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(v) : "memory");
 }
 
-// blocks 0 .. nblk-1 forward; sample 0 becomes X (the initial coefficient)
+// Forward sweep over blocks 0 .. nblk-1; sample 0 becomes X (the initial coefficient).
+// ckpt == nullptr: every block is written back (the anticausal sweep then reads the causal
+// result). Otherwise only the first and the last block are - the anticausal initial value
+// (iacc) reads from them - and of every block the value the recursion ENTERS it with is kept:
+// ckpt[64 * b + lane]. The backward sweep recomputes the causal result of a block from the
+// input and that value, with the same operations in the same order: one pass over the image
+// less (3 instead of 4 per axis) for one more recursion per sample.
+// vmcnt: the waits name a count that is never larger than the number of operations issued
+// behind the block's requests (extra stores only make a wait end a little later).
 template <bool GAIN, class T>
-__device__ __forceinline__ float stream_causal(const T &tl, float *smem, int nblk, bool active,
+__device__ __forceinline__ float stream_causal(const T &tl, float *smem, float *ckpt, int nblk, bool active,
                                                float g, float p, float X)
 {
+  typedef iir_bufs<T> B;
   const unsigned lds0 = (unsigned)(unsigned long long)(iir_lvoid)smem;
-  for (int b = 0; b < EU_IIR_AHEAD && b < nblk; b++) tl.request(iir_buf<T>(lds0, b), b);
+  for (int b = 0; b < EU_IIR_AHEAD && b < nblk; b++) tl.request(B::at(lds0, b), b);
   for (int b = 0; b < nblk; b++) {
     if (b + EU_IIR_AHEAD < nblk) {
-      tl.request(iir_buf<T>(lds0, b + EU_IIR_AHEAD), b + EU_IIR_AHEAD);
-      // behind the requests of block b: those of the AHEAD blocks after it and the stores of
-      // the min(b, AHEAD) blocks before it
-      if (b >= EU_IIR_AHEAD) iir_wait_vm<2 * T::OPS * EU_IIR_AHEAD>();
+      tl.request(B::at(lds0, b + EU_IIR_AHEAD), b + EU_IIR_AHEAD);
+      if (!ckpt && b >= EU_IIR_AHEAD) iir_wait_vm<2 * T::OPS * EU_IIR_AHEAD>();
       else iir_wait_vm<T::OPS * EU_IIR_AHEAD>();
     } else {
       iir_wait_vm<0>();
     }
-    iir_lptr tile = (iir_lptr)smem + (b % EU_IIR_BUFS) * T::FLOATS;
-    if (active) {
+    const bool keep = !ckpt || b == 0 || b == nblk - 1;
+    iir_lptr tile = (iir_lptr)smem + (b % EU_IIR_BUFS) * B::BUF;
+    if (ckpt && active) iir_store4(ckpt + b * 64, X);
+    if (active && !IIR_EXP(1)) {
       iir_lptr t = tile + tl.chain_off();
       float a[64];
 #pragma unroll
@@ -437,36 +472,54 @@ __device__ __forceinline__ float stream_causal(const T &tl, float *smem, int nbl
         if constexpr (GAIN) X = g * a[i] + p * X; else X = a[i] + p * X;
         a[i] = X;
       }
+      if (keep) {
 #pragma unroll
-      for (int i = 0; i < 64; i++) t[i * T::STRIDE] = a[i];
+        for (int i = 0; i < 64; i++) t[i * T::STRIDE] = a[i];
+      }
     }
-    tl.writeback(tile, b);
+    if (keep) tl.writeback(tile, b);
   }
   return X;
 }
 
-// blocks nblk-1 .. 0 backward; with `first` sample 64*nblk-1 becomes X (it is the line's last)
-template <class T>
-__device__ __forceinline__ void stream_anticausal(const T &tl, float *smem, int nblk, bool active,
-                                                  float p, float X, bool first)
+// Backward sweep over blocks nblk-1 .. 0; with `first` sample 64*nblk-1 becomes X (it is the
+// line's last). With ckpt the blocks between the first and the last hold the INPUT: their
+// causal result is recomputed from the checkpoint before the anticausal recursion runs over it.
+template <bool GAIN, class T>
+__device__ __forceinline__ void stream_anticausal(const T &tl, float *smem, const float *ckpt, int nblk, bool active,
+                                                  float g, float p, float X, bool first)
 {
+  typedef iir_bufs<T> B;
   const unsigned lds0 = (unsigned)(unsigned long long)(iir_lvoid)smem;
-  for (int j = 0; j < EU_IIR_AHEAD && j < nblk; j++) tl.request(iir_buf<T>(lds0, j), nblk - 1 - j);
+  auto request = [&](int k, int b) {
+    tl.request(B::at(lds0, k), b);
+    if (ckpt) iir_dma4(B::at(lds0, k) + T::FLOATS * 4, ckpt + b * 64);
+  };
+  for (int j = 0; j < EU_IIR_AHEAD && j < nblk; j++) request(j, nblk - 1 - j);
   for (int j = 0; j < nblk; j++) {
     const int b = nblk - 1 - j;
     if (j + EU_IIR_AHEAD < nblk) {
-      tl.request(iir_buf<T>(lds0, j + EU_IIR_AHEAD), b - EU_IIR_AHEAD);
+      request(j + EU_IIR_AHEAD, b - EU_IIR_AHEAD);
       if (j >= EU_IIR_AHEAD) iir_wait_vm<2 * T::OPS * EU_IIR_AHEAD>();
       else iir_wait_vm<T::OPS * EU_IIR_AHEAD>();
     } else {
       iir_wait_vm<0>();
     }
-    iir_lptr tile = (iir_lptr)smem + (j % EU_IIR_BUFS) * T::FLOATS;
-    if (active) {
+    const bool redo = ckpt && b != 0 && b != nblk - 1;
+    iir_lptr tile = (iir_lptr)smem + (j % EU_IIR_BUFS) * B::BUF;
+    if (active && !IIR_EXP(1)) {
       iir_lptr t = tile + tl.chain_off();
       float a[64];
 #pragma unroll
       for (int i = 63; i >= 0; i--) a[i] = t[i * T::STRIDE];
+      if (redo) {
+        float C = tile[T::FLOATS + tl.lane];
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+          if constexpr (GAIN) C = g * a[i] + p * C; else C = a[i] + p * C;
+          a[i] = C;
+        }
+      }
       {
         float Y = p * (X - a[63]);
         X = (first && j == 0) ? X : Y;
@@ -481,9 +534,11 @@ __device__ __forceinline__ void stream_anticausal(const T &tl, float *smem, int 
   }
 }
 
-// solve_line with the block part of every sweep streamed; M >= 64
+// solve_line with the block part of every sweep streamed; M >= 64. ckpt: this lane's
+// checkpoint column (64 floats per block) or nullptr
 template <class Ln, class T>
-__device__ void solve_line_stream(const iir_dev &f, const Ln &x, const T &tl, int M, bool active, float *smem)
+__device__ void solve_line_stream(const iir_dev &f, const Ln &x, const T &tl, int M, bool active, float *smem,
+                                  float *ckpt)
 {
   const int nblk = M / 64, n1 = nblk * 64;
   const float g = f.gain;
@@ -491,8 +546,8 @@ __device__ void solve_line_stream(const iir_dev &f, const Ln &x, const T &tl, in
     const float p = f.pole[k];
     float X = 0.0f;
     if (active) { X = icc(f, x, M, k); if (k == 0) X = g * X; }
-    if (k == 0) X = stream_causal<true>(tl, smem, nblk, active, g, p, X);
-    else X = stream_causal<false>(tl, smem, nblk, active, 1.0f, p, X);
+    if (k == 0) X = stream_causal<true>(tl, smem, ckpt, nblk, active, g, p, X);
+    else X = stream_causal<false>(tl, smem, ckpt, nblk, active, 1.0f, p, X);
     if (active)
       for (int n = n1; n < M; n++) {
         if (k == 0) X = g * x.get(n) + p * X; else X = x.get(n) + p * X;
@@ -507,51 +562,78 @@ __device__ void solve_line_stream(const iir_dev &f, const Ln &x, const T &tl, in
         for (int n = M - 2; n >= n1; n--) { X = p * (X - x.get(n)); x.put(n, X); }
       }
     }
-    stream_anticausal(tl, smem, nblk, active, p, X, !tail);
+    if (k == 0) stream_anticausal<true>(tl, smem, ckpt, nblk, active, g, p, X, !tail);
+    else stream_anticausal<false>(tl, smem, ckpt, nblk, active, 1.0f, p, X, !tail);
     iir_wait_vm<0>();
   }
 }
 
-template <int NCH, int R>
-__global__ __launch_bounds__(64) void filter_rows_stream_kernel(iir_dev f, float *base, long long line_stride, int len)
+// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), and every XCD has its own
+// L2. Column groups that are neighbours in memory share the cache lines at their common edge
+// (a row of the container does not start on a line boundary): give every XCD a CONTIGUOUS range
+// of groups, so that both halves of such a line are read and - what matters - written through
+// the same L2 within a few microseconds and leave it as one full line.
+__device__ __forceinline__ unsigned iir_xcd_group(unsigned b, unsigned n)
 {
-  __shared__ __attribute__((aligned(16))) float smem[EU_IIR_BUFS * tile_rows<NCH, R>::FLOATS];
-  const int lane = threadIdx.x;
-  float *rows = base + (long long)blockIdx.x * R * line_stride;
+  const unsigned q = n / 8, r = n % 8, xcd = b % 8, idx = b / 8;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// A workgroup is blockDim.x / 64 INDEPENDENT wavefronts (no barrier anywhere), each with its own
+// group of lines and its own slice of the dynamic LDS.
+// ckpt: groups x (len / 64) x 64 floats of scratch, or nullptr
+extern __shared__ __attribute__((aligned(16))) float iir_dyn_lds[];
+
+template <int NCH, int R>
+__global__ __launch_bounds__(256) void filter_rows_stream_kernel(iir_dev f, float *base, long long line_stride, int len,
+                                                                float *ckpt, unsigned ngroups)
+{
+  const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), wpg = blockDim.x / 64;
+  const unsigned group = blockIdx.x * wpg + wave;
+  if (group >= ngroups) return;
+  float *smem = iir_dyn_lds + wave * (EU_IIR_BUFS * iir_bufs<tile_rows<NCH, R>>::BUF);
+  float *rows = base + (long long)group * R * line_stride;
   tile_rows<NCH, R> tl { rows + lane * 4, line_stride, lane };
   const bool active = lane < R * NCH;
   const int li = active ? lane / NCH : 0, c = lane % NCH;
   strided_line ln { rows + li * line_stride + c, NCH };
-  solve_line_stream(f, ln, tl, len, active, smem);
+  if (ckpt) ckpt += (long long)group * (len / 64) * 64 + lane;
+  solve_line_stream(f, ln, tl, len, active, smem, ckpt);
 }
 
 template <int L>
-__global__ __launch_bounds__(64) void filter_cols_stream_kernel(iir_dev f, float *base, long long es, int len)
+__global__ __launch_bounds__(256) void filter_cols_stream_kernel(iir_dev f, float *base, long long es, int len, float *ckpt,
+                                                                unsigned ngroups)
 {
-  __shared__ __attribute__((aligned(16))) float smem[EU_IIR_BUFS * tile_cols<L, false>::FLOATS];
-  const int lane = threadIdx.x;
-  float *cols = base + (long long)blockIdx.x * L;
+  const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), wpg = blockDim.x / 64;
+  const unsigned group = iir_xcd_group(blockIdx.x, gridDim.x) * wpg + wave;
+  if (group >= ngroups) return;
+  float *smem = iir_dyn_lds + wave * (EU_IIR_BUFS * iir_bufs<tile_cols<L, false>>::BUF);
+  float *cols = base + (long long)group * L;
   tile_cols<L, false> tl { cols + (lane % (L / 4)) * 4, nullptr, es, 0, lane };
   const bool active = lane < L;
   strided_line ln { cols + (active ? lane : 0), es };
-  solve_line_stream(f, ln, tl, len, active, smem);
+  if (ckpt) ckpt += (long long)group * (len / 64) * 64 + lane;
+  solve_line_stream(f, ln, tl, len, active, smem, ckpt);
 }
 
 template <int L>
-__global__ __launch_bounds__(64) void filter_stacked_stream_kernel(iir_dev f, float *core, long long down_off,
-                                                                  long long row_es, int H)
+__global__ __launch_bounds__(256) void filter_stacked_stream_kernel(iir_dev f, float *core, long long down_off,
+                                                                   long long row_es, int H, float *ckpt, unsigned ngroups)
 {
-  __shared__ __attribute__((aligned(16))) float smem[EU_IIR_BUFS * tile_cols<L, true>::FLOATS];
-  const int lane = threadIdx.x;
-  float *cols = core + (long long)blockIdx.x * L;
+  const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), wpg = blockDim.x / 64;
+  const unsigned group = iir_xcd_group(blockIdx.x, gridDim.x) * wpg + wave;
+  if (group >= ngroups) return;
+  float *smem = iir_dyn_lds + wave * (EU_IIR_BUFS * iir_bufs<tile_cols<L, true>>::BUF);
+  float *cols = core + (long long)group * L;
   float *mine = cols + (lane % (L / 4)) * 4;
   tile_cols<L, true> tl { mine, mine + down_off, row_es, H, lane };
   const bool active = lane < L;
   float *own = cols + (active ? lane : 0);
   stacked_line ln { own, own + down_off, row_es, H };
-  solve_line_stream(f, ln, tl, 2 * H, active, smem);
+  if (ckpt) ckpt += (long long)group * (2 * H / 64) * 64 + lane;
+  solve_line_stream(f, ln, tl, 2 * H, active, smem, ckpt);
 }
-
 
 // zimt/brace.h:134-330 for one axis; slices span the whole container
 __device__ __forceinline__ long long brace_source(int bc, long long lsz, long long m,
@@ -806,28 +888,88 @@ inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1)
 
 // EU_HIP_IIR_STREAM=0: the one-thread-per-line kernels only (the form the streamed ones are
 // checked against on the device, tests/test_gpu_prefilter_stream.py)
-int iir_stream_on()   // bit 0: rows, bit 1: columns
+int iir_stream_on()   // bit 0: rows, bit 1: columns, bit 2: checkpoints + recomputation (3 passes per axis)
 {
+#ifdef EU_IIR_EXPERIMENT
+  const char *d = getenv("EU_HIP_IIR_EXP");
+  int dv = d ? atoi(d) : 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(iir_exp), &dv, sizeof dv);
+#endif
   const char *e = getenv("EU_HIP_IIR_STREAM");
-  return e ? atoi(e) : 3;
+  return e ? atoi(e) : 7;
 }
 
-constexpr int IIR_ROWS = 8, IIR_COLS = 32;
+// lines per wavefront: few, so that the lines of a large image make more wavefronts than the
+// chip has SIMDs (1024) and a SIMD has two recursions to alternate between
+int iir_env(const char *name, int dflt)
+{
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// Scratch for the checkpoints of the streamed sweeps (stream_causal): groups x blocks x 64 floats,
+// stream-ordered allocation. Only when every pole's horizon lies inside the first block (iacc
+// reads the causal result of that many samples) and EU_HIP_IIR_STREAM has bit 2 set.
+float *iir_ckpt_alloc(const iir_dev &f, long long groups, int len, hipStream_t st)
+{
+  if (!(iir_stream_on() & 4) || len / 64 < 3) return nullptr;
+  for (int k = 0; k < f.npoles; k++) if (f.horizon[k] >= 64) return nullptr;
+  void *p = nullptr;
+  if (hipMallocAsync(&p, (size_t)groups * (size_t)(len / 64) * 64 * sizeof(float), st) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return (float *)p;
+}
+void iir_ckpt_free(float *p, hipStream_t st) { if (p) (void)hipFreeAsync(p, st); }
+
+// groups of lines -> workgroups of `wpg` independent wavefronts with `wave_lds` bytes each
+template <class K, class... A>
+void launch_stream(K kernel, unsigned groups, size_t wave_lds, hipStream_t st, A... args)
+{
+  // measured: 1, 2 and 4 wavefronts per workgroup take the same time (the sweeps are not bound by
+  // where the wavefronts sit); 1 keeps the LDS request under 64 KB
+  int wpg = iir_env("EU_HIP_IIR_WPG", 1);
+  if (wpg < 1 || wpg > 4) wpg = 1;
+  while (wpg > 1 && wpg * wave_lds > 160 * 1024) wpg--;
+  const size_t lds = wpg * wave_lds;
+  (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kernel, dim3((groups + wpg - 1) / wpg), dim3(64 * wpg), lds, st, args..., groups);
+}
+
+template <int NCH, int R>
+void launch_rows_nr(const iir_dev &f, float *base, unsigned groups, long long line_stride, int len, float *ck, hipStream_t st)
+{
+  launch_stream(filter_rows_stream_kernel<NCH, R>, groups,
+                sizeof(float) * EU_IIR_BUFS * iir_bufs<tile_rows<NCH, R>>::BUF, st, f, base, line_stride, len, ck);
+}
+
+template <int NCH>
+unsigned launch_rows_nch(int R, const iir_dev &f, float *base, long long nl, long long line_stride, int len, hipStream_t st)
+{
+  const unsigned groups = (unsigned)(nl / R);
+  float *ck = iir_ckpt_alloc(f, groups, len, st);
+  if (R == 4) launch_rows_nr<NCH, 4>(f, base, groups, line_stride, len, ck, st);
+  else launch_rows_nr<NCH, 8>(f, base, groups, line_stride, len, ck, st);
+  iir_ckpt_free(ck, st);
+  return groups;
+}
 
 // nl rows of len samples x nch channels (es = nch), rows line_stride floats apart
 void launch_filter_rows(const iir_dev &f, float *base, long long nl, int nch, long long line_stride,
                         int len, hipStream_t st)
 {
   long long done = 0;
-  if ((iir_stream_on() & 1) && len >= 64 && nch >= 1 && nch <= 4 && nl >= IIR_ROWS) {
-    const unsigned groups = (unsigned)(nl / IIR_ROWS);
+  const int R = iir_env("EU_HIP_IIR_ROWS", 8) == 4 ? 4 : 8;
+  if ((iir_stream_on() & 1) && len >= 64 && nch >= 1 && nch <= 4 && nl >= R) {
+    unsigned groups;
     switch (nch) {
-      case 1: hipLaunchKernelGGL((filter_rows_stream_kernel<1, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len); break;
-      case 2: hipLaunchKernelGGL((filter_rows_stream_kernel<2, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len); break;
-      case 3: hipLaunchKernelGGL((filter_rows_stream_kernel<3, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len); break;
-      default: hipLaunchKernelGGL((filter_rows_stream_kernel<4, IIR_ROWS>), dim3(groups), dim3(64), 0, st, f, base, line_stride, len);
+      case 1: groups = launch_rows_nch<1>(R, f, base, nl, line_stride, len, st); break;
+      case 2: groups = launch_rows_nch<2>(R, f, base, nl, line_stride, len, st); break;
+      case 3: groups = launch_rows_nch<3>(R, f, base, nl, line_stride, len, st); break;
+      default: groups = launch_rows_nch<4>(R, f, base, nl, line_stride, len, st);
     }
-    done = (long long)groups * IIR_ROWS;
+    done = (long long)groups * R;
   }
   if (done < nl)
     hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for((nl - done) * nch, 64)), dim3(64), 0, st, f,
@@ -838,10 +980,14 @@ void launch_filter_rows(const iir_dev &f, float *base, long long nl, int nch, lo
 void launch_filter_cols(const iir_dev &f, float *base, long long nfloats, long long es, int len, hipStream_t st)
 {
   long long done = 0;
-  if ((iir_stream_on() & 2) && len >= 64 && nfloats >= IIR_COLS) {
-    const unsigned groups = (unsigned)(nfloats / IIR_COLS);
-    hipLaunchKernelGGL((filter_cols_stream_kernel<IIR_COLS>), dim3(groups), dim3(64), 0, st, f, base, es, len);
-    done = (long long)groups * IIR_COLS;
+  const int L = iir_env("EU_HIP_IIR_COLS", 32) == 16 ? 16 : 32;
+  if ((iir_stream_on() & 2) && len >= 64 && nfloats >= L) {
+    const unsigned groups = (unsigned)(nfloats / L);
+    float *ck = iir_ckpt_alloc(f, groups, len, st);
+    if (L == 16) launch_stream(filter_cols_stream_kernel<16>, groups, sizeof(float) * EU_IIR_BUFS * iir_bufs<tile_cols<16, false>>::BUF, st, f, base, es, len, ck);
+    else launch_stream(filter_cols_stream_kernel<32>, groups, sizeof(float) * EU_IIR_BUFS * iir_bufs<tile_cols<32, false>>::BUF, st, f, base, es, len, ck);
+    iir_ckpt_free(ck, st);
+    done = (long long)groups * L;
   }
   if (done < nfloats)
     hipLaunchKernelGGL(filter_lines_kernel, dim3(blocks_for(nfloats - done, 64)), dim3(64), 0, st, f,
@@ -852,10 +998,14 @@ void launch_filter_cols(const iir_dev &f, float *base, long long nfloats, long l
 void launch_filter_stacked(const iir_dev &f, float *core, long long nfloats, long long row_es, int H, hipStream_t st)
 {
   long long done = 0;
-  if ((iir_stream_on() & 2) && 2 * H >= 64 && nfloats >= IIR_COLS) {
-    const unsigned groups = (unsigned)(nfloats / IIR_COLS);
-    hipLaunchKernelGGL((filter_stacked_stream_kernel<IIR_COLS>), dim3(groups), dim3(64), 0, st, f, core, nfloats, row_es, H);
-    done = (long long)groups * IIR_COLS;
+  const int L = iir_env("EU_HIP_IIR_COLS", 32) == 16 ? 16 : 32;
+  if ((iir_stream_on() & 2) && 2 * H >= 64 && nfloats >= L) {
+    const unsigned groups = (unsigned)(nfloats / L);
+    float *ck = iir_ckpt_alloc(f, groups, 2 * H, st);
+    if (L == 16) launch_stream(filter_stacked_stream_kernel<16>, groups, sizeof(float) * EU_IIR_BUFS * iir_bufs<tile_cols<16, true>>::BUF, st, f, core, nfloats, row_es, H, ck);
+    else launch_stream(filter_stacked_stream_kernel<32>, groups, sizeof(float) * EU_IIR_BUFS * iir_bufs<tile_cols<32, true>>::BUF, st, f, core, nfloats, row_es, H, ck);
+    iir_ckpt_free(ck, st);
+    done = (long long)groups * L;
   }
   if (done < nfloats)
     hipLaunchKernelGGL(filter_stacked_kernel, dim3(blocks_for(nfloats - done, 64)), dim3(64), 0, st, f,

@@ -25,9 +25,15 @@ def same(a, b, what):
 
 
 class generic_kernels:
+    """EU_HIP_IIR_STREAM: 0 one thread per line; 3 streamed, four passes per axis; 7 (default) streamed
+    with checkpoints, the causal result recomputed in the backward sweep"""
+
+    def __init__(self, mode="0"):
+        self.mode = mode
+
     def __enter__(self):
         self.keep = os.environ.get("EU_HIP_IIR_STREAM")
-        os.environ["EU_HIP_IIR_STREAM"] = "0"
+        os.environ["EU_HIP_IIR_STREAM"] = self.mode
 
     def __exit__(self, *a):
         if self.keep is None:
@@ -48,10 +54,11 @@ def test_spherical_streamed_prefilter(sw, sh, degree, nch):
     g.release()
     o = jobs.OracleSource(euo.SPHERICAL, sw, sh, 360.0, img, degree)
     same(got, o.container, f"spherical {sw}x{sh}x{nch} degree {degree} vs oracle")
-    with generic_kernels():
-        g2 = ea.Source.load(fct, img, degree)
-        same(got, g2.download(), "streamed vs one thread per line")
-        g2.release()
+    for mode in ("0", "3"):
+        with generic_kernels(mode):
+            g2 = ea.Source.load(fct, img, degree)
+            same(got, g2.download(), f"streamed vs EU_HIP_IIR_STREAM={mode}")
+            g2.release()
 
 
 @pytest.mark.parametrize("nch", [1, 3, 4])

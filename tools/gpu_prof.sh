@@ -8,12 +8,13 @@ OUT="$R/gpurun_out/$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS} > "$OUT/trace.log" 2>&1 || echo "trace failed"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS} > "$OUT/trace.log" 2>&1 || echo "trace failed"
 i=0
 IFS='|' read -ra GS <<< "${PMC_GROUPS}"
 for ctrs in "${GS[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/p$i" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > "$OUT/p$i.log" 2>&1 || echo "pass $i failed: $ctrs"
+  echo "pass $i: $ctrs" >> "$OUT/progress.txt"
+  timeout -k 5 180 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/p$i" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > "$OUT/p$i.log" 2>&1 || echo "pass $i failed: $ctrs"
 done
 cd "$R"
 python3 - "$OUT" <<'PY'
@@ -29,7 +30,7 @@ with open(out + '/summary.txt', 'w') as o:
     agg = collections.defaultdict(list)
     for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'eu_' in r['Kernel_Name']:
+            if 'eu_' in r['Kernel_Name'] or 'filter_' in r['Kernel_Name']:
                 agg[(r['Kernel_Name'].split('(')[0][-46:], r['Counter_Name'])].append(float(r['Counter_Value']))
     if agg: emit("# counters: mean per dispatch")
     for k, v in sorted(agg.items()):
