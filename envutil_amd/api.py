@@ -50,10 +50,12 @@ class Target(C.Structure):
                 ("crop_x0", C.c_int32), ("crop_y0", C.c_int32),
                 ("crop_w", C.c_int32), ("crop_h", C.c_int32),
                 ("out_format", C.c_int32),
-                ("band_rows", C.c_int32), ("band_count", C.c_int32), ("band_index", C.c_int32)]
+                ("band_rows", C.c_int32), ("band_count", C.c_int32), ("band_index", C.c_int32),
+                ("synopsis", C.c_int32)]
 
 
 OUT_FLOAT, OUT_SRGBA8 = 0, 1
+SYN_PANORAMA, SYN_HDR_MERGE = 0, 1
 
 
 def lib_path():
@@ -299,13 +301,17 @@ class arguments:
     def __init__(self, projection, width, height, hfov, yaw=0.0, pitch=0.0, roll=0.0,
                  spline_degree=1, prefilter_degree=None, twine=0, twine_width=1.0,
                  twine_sigma=0.0, twine_threshold=0.0, support_min=8, tile_size=64,
-                 crop=None, tethered=False):
+                 crop=None, tethered=False, synopsis="panorama"):
         # store_cropped + p_crop_x0/x1/y0/y1 (envutil_basic.h:684-687) as
         # (x0, x1, y0, y1); tethered: the job writes packed sRGBA8 words
         # (args.p_screen_data, envutil_payload.cc:524-530)
         self.store_cropped = crop is not None
         self.p_crop = tuple(crop) if crop is not None else None
         self.tethered = tethered
+        # args.synopsis (envutil_main.cc:232): how several facets are composed, "panorama" or "hdr_merge"
+        if synopsis not in ("panorama", "hdr_merge"):
+            raise ValueError("synopsis must be panorama or hdr_merge")
+        self.synopsis = synopsis
         self.projection = projection
         self.width, self.height = width, height
         self.hfov = hfov
@@ -341,6 +347,7 @@ class arguments:
             x0, x1, y0, y1 = self.p_crop
             t.crop_x0, t.crop_y0, t.crop_w, t.crop_h = x0, y0, x1 - x0, y1 - y0
         t.out_format = OUT_SRGBA8 if self.tethered else OUT_FLOAT
+        t.synopsis = SYN_HDR_MERGE if self.synopsis == "hdr_merge" else SYN_PANORAMA
         nrows = self.out_height
         if band is not None and band[1] > 1:
             t.band_rows, t.band_count, t.band_index = band

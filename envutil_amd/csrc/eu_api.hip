@@ -330,6 +330,8 @@ int check_target(const eu_target *t)
     return fail(EU_ERR_ARGUMENT, "bad twining tap table");
   if ((t->projection == EU_CUBEMAP || t->projection == EU_BIATAN6) && t->height != 6 * t->width)
     return fail(EU_ERR_ARGUMENT, "cubemap targets are 1:6");
+  if (t->synopsis != EU_SYN_PANORAMA && t->synopsis != EU_SYN_HDR_MERGE)
+    return fail(EU_ERR_ARGUMENT, "unknown synopsis");
   if (t->out_format != EU_OUT_FLOAT && t->out_format != EU_OUT_SRGBA8)
     return fail(EU_ERR_ARGUMENT, "unknown output format");
   if (t->out_format == EU_OUT_SRGBA8 && t->stage)
@@ -422,6 +424,7 @@ struct multi_params {
   long long out_stride;
   int tiles_x, tiles_y;
   int band_shift, band_count, band_index;
+  int hdr, hdr_low, hdr_high;
 };
 
 // fuse() for several facets (envutil_payload.cc:2139-2180, :2240-2281): one
@@ -497,6 +500,17 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   }
   p->form = g.mplan_form; p->norm_mode = g.mplan_norm; p->twine = twine; p->ntaps = t->ntaps;
   p->nch = t->nchannels; p->nfct = nsrc; p->plus = (t->nchannels == 2 || t->nchannels == 4);
+  p->hdr = t->synopsis == EU_SYN_HDR_MERGE;
+  {
+    // _hdr_merge_syn ctor (envutil_payload.cc:1346-1376): the first strict minimum / maximum of brighten
+    float lowest = 100000.0f, highest = -1.0f;
+    p->hdr_low = p->hdr_high = -1;
+    for (int f = 0; f < nsrc; f++) {
+      const float b = srcs[f]->sd.brighten;
+      if (b < lowest) { lowest = b; p->hdr_low = f; }
+      if (b > highest) { highest = b; p->hdr_high = f; }
+    }
+  }
   p->col = g.mcol; p->row = g.mrow; p->taps = g.mtaps; p->srcs = g.msrc;
   p->out = out_dev; p->out_stride = (long long)(row_stride_bytes / sizeof(float));
   *degree = s0->degree;

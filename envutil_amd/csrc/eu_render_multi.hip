@@ -5,6 +5,7 @@
 //   synopsis_t (twining)    envutil_payload.cc:587-691
 //   _voronoi_syn            envutil_payload.cc:762-957   (1 or 3 channels)
 //   _voronoi_syn_plus       envutil_payload.cc:964-1233  (alpha: 2 or 4 channels)
+//   _hdr_merge_syn          envutil_payload.cc:1325-1626 (args.synopsis == "hdr_merge")
 //
 // One thread per output pixel, 64x4 tiles like eu_render_kernel. The reference
 // takes three decisions per 16-lane VECTOR (which facets enter the layer list,
@@ -36,6 +37,7 @@ struct eu_multi_params {
   long long out_stride;
   int tiles_x, tiles_y;
   int band_shift, band_count, band_index;   // eu_frame_row
+  int hdr, hdr_low, hdr_high;               // _hdr_merge_syn: the facets that rule the shadows / the highlights
 };
 
 struct eu_pix { int x, y; };
@@ -287,6 +289,89 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
   }
 }
 
+// _hdr_merge_syn::get_quality for a grey value (envutil_payload.cc:1388-1446); kind 0 LOW, 1 MIDDLE, 2 HIGH
+__device__ __forceinline__ float eu_hdr_quality(float grey, float optimum, int kind)
+{
+  const bool large = grey > optimum;
+  float distance = fabsf(optimum - grey);
+  if (kind == 0 && !large) distance = 0.0f;
+  if (kind == 2 && large) distance = 0.0f;
+  const float proximity = optimum - distance;
+  return proximity / (optimum * optimum);
+}
+__device__ __forceinline__ float eu_std_max(float a, float b) { return a < b ? b : a; }
+
+// _hdr_merge_syn::operator() (envutil_payload.cc:1500-1622): EVERY facet is evaluated - a miss is a
+// zero pixel and takes part with the quality a zero pixel has -, quality-weighted sum, normalised.
+// The one per-VECTOR decision (all_of(alpha == 0) -> quality 0) is a ballot over the lane's group of 16.
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu_synopsis_hdr(const eu_multi_params &p, const eu_pix &px, bool live,
+                                                bool tap, float cx, float cy, float *out)
+{
+  constexpr bool alpha = NCH == 2 || NCH == 4;
+  constexpr int ncol = alpha ? NCH - 1 : NCH;
+  const int grp = (threadIdx.x & 63) >> 4;
+  const unsigned live_g = (unsigned)(__ballot(live) >> (16 * grp)) & 0xffffu;
+  float qsum = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) out[c] = 0.0f;
+#pragma unroll 1
+  for (int f = 0; f < p.nfct; f++) {
+    float rx, ry, rz, sx = 0.0f, sy = 0.0f;
+    int face;
+    eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+    const eu_src_dev &s = p.srcs[f];
+    bool hit = true, any = true;
+    if (!s.mask_all) {
+      // whole wavefront provably outside the facet's window: its pixel is zero without the exact test
+      const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+      hit = false;
+      any = __ballot(maybe) != 0;
+      if (any) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+    } else {
+      hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+    }
+    float v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) v[c] = 0.0f;
+    // a wavefront without a hit needs no gathers - unless the facet has another channel count: a miss
+    // is then the ADAPTED zero pixel (repix_t gives it alpha 1)
+    if (s.nch != NCH || (any && __ballot(hit))) eu_env_facet<NCH, DEG>(s, hit, sx, sy, v);
+    const int kind = f == p.hdr_low ? 0 : (f == p.hdr_high ? 2 : 1);
+    const float optimum = 0.5f * s.brighten;
+    float grey;
+    if constexpr (ncol == 1) grey = v[0];
+    else grey = eu_std_max(v[0], eu_std_max(v[1], v[2]));
+    float q = eu_hdr_quality(grey, optimum, kind);
+    if constexpr (alpha) {
+      const float a = v[NCH - 1];
+      const unsigned zero_g = (unsigned)(__ballot(live && a == 0.0f) >> (16 * grp)) & 0xffffu;
+      q = zero_g == live_g ? 0.0f : a * q;
+    }
+    qsum = qsum + q;
+    if constexpr (!alpha) {
+#pragma unroll
+      for (int c = 0; c < NCH; c++) out[c] = out[c] + v[c] * q;
+    } else {
+      const float a = v[NCH - 1];
+#pragma unroll
+      for (int c = 0; c < ncol; c++) {
+        float d = 0.0f;
+        if (a > 0.000001f) d = v[c] / a;
+        out[c] = out[c] + d * q;
+      }
+      out[NCH - 1] = eu_std_max(out[NCH - 1], a);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < ncol; c++) {
+    float t = out[c] / qsum;
+    if (!(qsum > 0.0f)) t = 0.0f;
+    if constexpr (alpha) t = t * out[NCH - 1];
+    out[c] = t;
+  }
+}
+
 // The synopsis kernels are bound by the latency of their gathers (six 1-GB sources,
 // little locality) more than by anything else: capping the registers for 5 waves per
 // SIMD (a few spills) beats the 2-3 waves the allocator settles on by itself - config 5:
@@ -296,7 +381,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
 #endif
 #define EU_MULTI_OCC __attribute__((amdgpu_waves_per_eu(EU_MULTI_WAVES, EU_MULTI_WAVES)))
 
-template <int NCH, int DEG, bool PLUS>
+template <int NCH, int DEG, bool PLUS, bool HDR = false>
 __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const eu_multi_params p)
 {
   extern __shared__ float eu_dyn_lds[];
@@ -318,14 +403,16 @@ __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const
   sl.sy = sl.sx + p.nfct * 256;
   float out[NCH];
   if (!p.twine) {
-    eu_synopsis<NCH, DEG, PLUS>(p, px, live, false, 0.0f, 0.0f, sl, out);
+    if constexpr (HDR) eu_synopsis_hdr<NCH, DEG>(p, px, live, false, 0.0f, 0.0f, out);
+    else eu_synopsis<NCH, DEG, PLUS>(p, px, live, false, 0.0f, 0.0f, sl, out);
   } else {
 #pragma unroll
     for (int c = 0; c < NCH; c++) out[c] = 0.0f;
     for (int k = 0; k < p.ntaps; k++) {
       const float cx = p.taps[3 * k], cy = p.taps[3 * k + 1], cw = p.taps[3 * k + 2];
       float help[NCH];
-      eu_synopsis<NCH, DEG, PLUS>(p, px, live, true, cx, cy, sl, help);
+      if constexpr (HDR) eu_synopsis_hdr<NCH, DEG>(p, px, live, true, cx, cy, help);
+      else eu_synopsis<NCH, DEG, PLUS>(p, px, live, true, cx, cy, sl, help);
 #pragma unroll
       for (int c = 0; c < NCH; c++) out[c] = out[c] + cw * help[c];
     }
@@ -340,7 +427,17 @@ static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), block(256);
   // alpha compositing keeps z (and, for up to EU_MULTI_KEEP facets, the source
   // coordinate) of every facet per thread in LDS
-  const size_t lds = PLUS ? (size_t)(p.nfct <= EU_MULTI_KEEP ? 3 : 1) * p.nfct * 256 * sizeof(float) : 0;
+  const size_t lds = PLUS && !p.hdr ? (size_t)(p.nfct <= EU_MULTI_KEEP ? 3 : 1) * p.nfct * 256 * sizeof(float) : 0;
+  if (p.hdr) {
+    switch (degree) {
+      case 0: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 0, PLUS, true>), grid, block, lds, st, p); break;
+      case 1: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 1, PLUS, true>), grid, block, lds, st, p); break;
+      case 2: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 2, PLUS, true>), grid, block, lds, st, p); break;
+      case 3: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 3, PLUS, true>), grid, block, lds, st, p); break;
+      default: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, PLUS, true>), grid, block, lds, st, p); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   switch (degree) {
     case 0: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 0, PLUS>), grid, block, lds, st, p); break;
     case 1: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 1, PLUS>), grid, block, lds, st, p); break;

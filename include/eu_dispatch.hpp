@@ -182,9 +182,11 @@ struct hip_dispatch : public dispatch_base
     if (projection != args.projection) return EU_ERR_ARGUMENT;
     if ((ninputs == 9) != !args.twine_spread.empty()) return EU_ERR_ARGUMENT;
     if (args.tethered ? !args.p_screen_data : !args.p_output) return EU_ERR_ARGUMENT;
-    // outside this path: unstitching, masks, lens crops, translated facets, the
-    // other synopsis modes - the reference's CPU dispatch keeps them
-    if (args.single >= 0 || !args.split.empty() || args.synopsis != "panorama") return EU_ERR_UNSUPPORTED;
+    // outside this path: unstitching, masks, lens crops, translated facets - the
+    // reference's CPU dispatch keeps them; an unknown synopsis is the reference's assert(false)
+    // (envutil_payload.cc:2316-2318)
+    if (args.synopsis != "panorama" && args.synopsis != "hdr_merge") return EU_ERR_ARGUMENT;
+    if (args.single >= 0 || !args.split.empty()) return EU_ERR_UNSUPPORTED;
     for (const auto &fct : args.facet_spec_v)
       if (fct.has_pto_mask || fct.has_lens_crop || fct.masked != -1 || fct.tr_x != 0.0 || fct.tr_y != 0.0 ||
           fct.tr_z != 0.0 || fct.tp_y != 0.0 || fct.tp_p != 0.0 || fct.tp_r != 0.0)
@@ -221,6 +223,7 @@ struct hip_dispatch : public dispatch_base
       t.crop_x0 = args.p_crop_x0; t.crop_y0 = args.p_crop_y0; t.crop_w = w; t.crop_h = h;
     }
     t.row_begin = 0; t.row_end = h; t.stage = 0;
+    t.synopsis = args.synopsis == "hdr_merge" ? EU_SYN_HDR_MERGE : EU_SYN_PANORAMA;
     if (args.tethered) {
       t.out_format = EU_OUT_SRGBA8;
       return eu_hip_render(&t, srcs.data(), int(srcs.size()), (float *)args.p_screen_data,

@@ -120,6 +120,11 @@ typedef struct eu_target {
    * row_begin/row_end and the output buffer then count LOCAL rows
    * (eu_hip_band_rows tells how many there are). band_count <= 1: off.       */
   int32_t band_rows, band_count, band_index;
+  /* args.synopsis (envutil_main.cc:232, dispatched at envutil_payload.cc:2302-2318): how a job
+   * with several facets composes them. EU_SYN_PANORAMA: voronoi_syn (1/3 channels) or
+   * voronoi_syn_plus (2/4 channels); EU_SYN_HDR_MERGE: _hdr_merge_syn (envutil_payload.cc:
+   * 1325-1626), the quality-weighted sum of ALL facets. Ignored for single-facet jobs.        */
+  int32_t synopsis;
 } eu_target;
 
 /* How the library would lay the job's rows out (eu_api.hip: launch-level choice between
@@ -139,6 +144,7 @@ unsigned long long eu_hip_launch_count(void);
 int  eu_hip_band_rows(int height, int band_rows, int band_count, int band_index);
 
 enum { EU_OUT_FLOAT = 0, EU_OUT_SRGBA8 = 1 };
+enum { EU_SYN_PANORAMA = 0, EU_SYN_HDR_MERGE = 1 };
 
 /* ---- device / lifecycle ------------------------------------------------- */
 int  eu_hip_device_count(void);

@@ -1467,14 +1467,76 @@ static int mount_mask(const mount_t *m, const float *ray)
 
 typedef struct {
   int nfct, nch, plus;
+  int hdr, hdr_low, hdr_high;          /* _hdr_merge_syn: facet that rules the shadows / the highlights */
   mount_t mnt[EUO_MAX_FACETS];
   float recip_step[EUO_MAX_FACETS];
+  float optimum[EUO_MAX_FACETS];       /* 0.5f * brighten, envutil_payload.cc:1364 */
 } syn_t;
+
+/* _hdr_merge_syn::get_quality for a grey value (envutil_payload.cc:1388-1446): kind 0 LOW, 1 MIDDLE, 2 HIGH */
+static float hdr_quality(float grey, float optimum, int kind)
+{
+  int grey_is_large = grey > optimum;
+  float distance = fabsf(optimum - grey);
+  if (kind == 0 && !grey_is_large) distance = 0.0f;
+  if (kind == 2 && grey_is_large) distance = 0.0f;
+  float proximity = optimum - distance;
+  return proximity / (optimum * optimum);
+}
+static float std_max(float a, float b) { return a < b ? b : a; }   /* std::max, broadcast per lane */
+
+/* _hdr_merge_syn::operator() (envutil_payload.cc:1500-1622): EVERY facet is evaluated (a miss is a
+ * zero pixel and takes part with the quality of a zero pixel), quality-weighted sum, normalised */
+static void synopsis_hdr(const syn_t *sy, float rays[][EUO_LANES][3], int n, float px[][4])
+{
+  int nf = sy->nfct, nch = sy->nch;
+  float qsum[EUO_LANES];
+  for (int l = 0; l < n; l++) { qsum[l] = 0.0f; for (int c = 0; c < 4; c++) px[l][c] = 0.0f; }
+  for (int f = 0; f < nf; f++) {
+    float v[EUO_LANES][4];
+    int kind = f == sy->hdr_low ? 0 : (f == sy->hdr_high ? 2 : 1);
+    float opt = sy->optimum[f];
+    for (int l = 0; l < n; l++) env_eval(&sy->mnt[f], rays[f][l], nch, v[l], NULL);
+    int all_transparent = 1;
+    if (nch == 2 || nch == 4)
+      for (int l = 0; l < n; l++) if (!(v[l][nch - 1] == 0.0f)) all_transparent = 0;
+    for (int l = 0; l < n; l++) {
+      float q;
+      if (nch == 1) q = hdr_quality(v[l][0], opt, kind);
+      else if (nch == 3) q = hdr_quality(std_max(v[l][0], std_max(v[l][1], v[l][2])), opt, kind);
+      else {
+        float grey = nch == 2 ? v[l][0] : std_max(v[l][0], std_max(v[l][1], v[l][2]));
+        q = all_transparent ? 0.0f : v[l][nch - 1] * hdr_quality(grey, opt, kind);
+      }
+      qsum[l] += q;
+      if (nch == 1 || nch == 3) {
+        for (int c = 0; c < nch; c++) px[l][c] += v[l][c] * q;
+      } else {
+        float a = v[l][nch - 1];
+        for (int c = 0; c < nch - 1; c++) {
+          float d = 0.0f;
+          if (a > 0.000001f) d = v[l][c] / a;
+          px[l][c] += d * q;
+        }
+        px[l][nch - 1] = std_max(px[l][nch - 1], a);
+      }
+    }
+  }
+  for (int l = 0; l < n; l++) {
+    int ncol = (nch == 2 || nch == 4) ? nch - 1 : nch;
+    for (int c = 0; c < ncol; c++) {
+      px[l][c] /= qsum[l];
+      if (!(qsum[l] > 0.0f)) px[l][c] = 0.0f;
+      if (ncol != nch) px[l][c] *= px[l][nch - 1];
+    }
+  }
+}
 
 /* rays[f][lane][3] -> px[lane][nch] for n valid lanes */
 static void synopsis_group(const syn_t *sy, float rays[][EUO_LANES][3], int n, float px[][4])
 {
   int nf = sy->nfct, nch = sy->nch;
+  if (sy->hdr) { synopsis_hdr(sy, rays, n, px); return; }
   if (!sy->plus) {
     /* _voronoi_syn: champion = facet with the largest z * recip_step among the
      * facets the ray hits; strict '>' keeps the earlier facet on ties */
@@ -1649,6 +1711,18 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
       for (int v = 0; v < 3; v++) { st[3 * f + v].x_off = job->crop_x0; st[3 * f + v].y_off = job->crop_y0; }
     mount_init(&sy->mnt[f], &srcs[f]);
     sy->recip_step[f] = (float)(1.0 / srcs[f].step);
+    sy->optimum[f] = 0.5f * (float)srcs[f].brighten;
+  }
+  sy->hdr = job->synopsis == 1;
+  {
+    /* _hdr_merge_syn ctor (envutil_payload.cc:1346-1376): first strict minimum / maximum of brighten */
+    float lowest = 100000.0f, highest = -1.0f;
+    sy->hdr_low = sy->hdr_high = -1;
+    for (int f = 0; f < nsrc; f++) {
+      float b = (float)srcs[f].brighten;
+      if (b < lowest) { lowest = b; sy->hdr_low = f; }
+      if (b > highest) { highest = b; sy->hdr_high = f; }
+    }
   }
   int twining = job->ntaps > 0;
   float *taps = NULL;

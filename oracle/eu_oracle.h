@@ -89,6 +89,9 @@ typedef struct {
   /* 1: 'act + to_screen_t' (envutil_payload.cc:251-413, :524-530): one packed
    * sRGBA8 uint32 per pixel; out is then a uint32 buffer, stride in words */
   int screen;
+  /* args.synopsis for several facets: 0 "panorama" (voronoi_syn / voronoi_syn_plus by channel
+   * count), 1 "hdr_merge" (_hdr_merge_syn, envutil_payload.cc:1325-1626) */
+  int synopsis;
 } euo_job;
 
 /* to_screen_t's LUT (256 knots of 255 * sRGB(i / 255), float) and one pixel */

@@ -163,6 +163,7 @@ def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8, nc
     j.row_end = args.height if row_end is None else row_end
     j.stage = stage
     j.nthreads = nthreads
+    j.synopsis = 1 if getattr(args, "synopsis", "panorama") == "hdr_merge" else 0
     w = args.width
     if getattr(args, "store_cropped", False):
         x0, x1, y0, y1 = args.p_crop

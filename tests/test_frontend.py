@@ -229,3 +229,34 @@ def test_command_line_to_pixels(demo, tmp_path):
     a = ea.arguments(ea.SPHERICAL, 300, 150, 360.0, spline_degree=1, twine=j["twine"], twine_width=j["twine_width"])
     assert j["twine"] >= 1 and len(j["spread"]) == len(a.twine_spread)
     assert fnv1a(jobs.oracle_render(a, [o0, o1])) == got
+
+
+@pytest.mark.gpu
+def test_hdr_merge_command_line_to_pixels(demo, tmp_path):
+    """--synopsis hdr_merge on an exposure bracket described by a PTO (Eev per image -> brighten,
+    envutil_main.cc:1003-1060): front end -> payload() -> the HIP hdr_merge kernel == the oracle"""
+    import euo
+    import jobs
+    from test_cpp_dispatch import fnv1a
+    (tmp_path / "bracket.pto").write_text(
+        'p f0 w240 h160 v80 n"TIFF"\n'
+        'i w200 h150 f0 v70 y0 p0 r0 Eev10 n"a.tif"\n'
+        'i w200 h150 f0 v70 y0.5 p0 r0 Eev12 n"b.tif"\n'
+        'i w200 h150 f0 v70 y0 p0.5 r0 Eev14 n"c.tif"\n')
+    j, tail = demo(["--pto", "bracket.pto", "--output", "o.tif", "--degree", "1", "--twine", "0",
+                    "--synopsis", "hdr_merge"],
+                   {"a.tif": (200, 150, 3), "b.tif": (200, 150, 3), "c.tif": (200, 150, 3)}, cwd=str(tmp_path), render=True)
+    assert j["ok"] and j["synopsis"] == "hdr_merge" and "rc 0" in tail, tail
+    got = tail.split("fnv1a")[1].strip()
+    br = [f["brighten"] for f in j["facets"]]
+    assert br == [f32(2.0 ** (e - 12.0)) for e in (10, 12, 14)]
+
+    def pixels(k, w, h, n):
+        y, x, c = np.indices((h, w, n))
+        return (np.float32(0.5) + np.float32(0.25) * ((x * 7 + y * 13 + c * 29 + k * 5) % 97).astype(np.float32)
+                / np.float32(97.0)).astype(np.float32)
+    views = [(0.0, 0.0), (0.5, 0.0), (0.0, 0.5)]
+    os_ = [jobs.OracleSource(euo.RECTILINEAR, 200, 150, 70.0, pixels(k, 200, 150, 3), 1, yaw=views[k][0], pitch=views[k][1],
+                             brighten=br[k]) for k in range(3)]
+    a = ea.arguments(ea.RECTILINEAR, 240, 160, 80.0, spline_degree=1, synopsis="hdr_merge")
+    assert fnv1a(jobs.oracle_render(a, os_)) == got
