@@ -30,7 +30,9 @@ class Facet(C.Structure):
                 ("has_lcp", C.c_int32),
                 ("a", C.c_double), ("b", C.c_double), ("c", C.c_double),
                 ("h", C.c_double), ("v", C.c_double), ("s", C.c_double),
-                ("shear_g", C.c_double), ("shear_t", C.c_double)]
+                ("shear_g", C.c_double), ("shear_t", C.c_double),
+                ("tr_x", C.c_double), ("tr_y", C.c_double), ("tr_z", C.c_double),
+                ("tp_y", C.c_double), ("tp_p", C.c_double), ("tp_r", C.c_double)]
 
 
 class Container(C.Structure):
@@ -190,7 +192,7 @@ class facet_spec:
     (envutil_main.cc:957-960)."""
 
     def __init__(self, projection, width, height, hfov, nchannels=3, yaw=0.0,
-                 pitch=0.0, roll=0.0, brighten=1.0, window=None, lens=None):
+                 pitch=0.0, roll=0.0, brighten=1.0, window=None, lens=None, translation=None):
         self.projection = projection
         self.width, self.height = width, height
         self.hfov = hfov
@@ -199,6 +201,8 @@ class facet_spec:
         self.brighten = brighten
         self.window = window or (width, height, 0, 0)
         self.lens = lens or {}          # PTO a, b, c, h, v, g (shear_g), t (shear_t)
+        # PTO TrX, TrY, TrZ as x, y, z (model space units), Tpy, Tpp as tp_y, tp_p (+ tp_r), degrees
+        self.translation = translation or {}
 
     def c_struct(self):
         f = Facet()
@@ -213,6 +217,8 @@ class facet_spec:
         for k, v in self.lens.items():
             setattr(f, {"g": "shear_g", "t": "shear_t"}.get(k, k), v)
         f.has_lcp = int(any(self.lens.get(k, 0.0) != 0.0 for k in "abc"))
+        f.tr_x, f.tr_y, f.tr_z = (self.translation.get(k, 0.0) for k in ("x", "y", "z"))
+        f.tp_y, f.tp_p, f.tp_r = (math.radians(self.translation.get(k, 0.0)) for k in ("tp_y", "tp_p", "tp_r"))
         return f
 
 

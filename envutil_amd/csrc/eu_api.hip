@@ -72,6 +72,7 @@ struct context {
   eu_src_dev seg_sd;
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
   hipStream_t last_user = nullptr;                // caller's stream of the last render (eu_hip_sync waits on it too)
+  eu_generic *mgen = nullptr; size_t mgen_cap = 0; // multi-facet jobs: the translated facets' transformations
   hipStream_t copy = nullptr;                     // D2H of a host-output frame, chunk by chunk
   hipEvent_t chunk_done[4] = { nullptr, nullptr, nullptr, nullptr };
   int *wl = nullptr; size_t wl_cap = 0;           // eu_render4.hip work list (count, done, tile ids)
@@ -356,6 +357,12 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   eu::mat3 r_fct = eu::make_r3(s->fct.roll, s->fct.pitch, s->fct.yaw, true);
   eu::mat3 basis = eu::rotate(r_cam, r_fct);
   // plan key: everything the tables depend on
+  // a facet with translation parameters: generic_stepper over tf_ex_facet (envutil_payload.cc:2095-2110,
+  // :2214-2224), normalised only under twining (deriv_stepper<..., generic_stepper, true>)
+  eu_generic gen;
+  memset(&gen, 0, sizeof gen);
+  if (eu::has_translation(s->fct) && !eu::make_generic(*t, s->fct, gen))
+    return fail(EU_ERR_UNSUPPORTED, "translated facet: no planar-to-ray functor for this target projection");
   std::vector<unsigned char> key(sizeof(eu_target) + 3 * sizeof(double) + 3 * sizeof(float) * (size_t)t->ntaps);
   {
     eu_target tk = *t;
@@ -404,6 +411,11 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     p->band_shift = band_shift_of(t->band_rows); p->band_count = t->band_count; p->band_index = t->band_index;
   }
   p->form = form; p->norm_mode = norm_mode;
+  if (gen.on) {                // the tables (planar x per column, planar y per row) are the same
+    p->form = EU_FORM_GENERIC;
+    p->norm_mode = twine ? EU_NORM_DIV : EU_NORM_NONE;
+    p->gen = gen;
+  }
   p->twine = twine; p->ntaps = t->ntaps; p->stage = t->stage; p->nch = s->nch;
   p->nch_out = t->nchannels;
   p->col = g.col; p->row = g.row; p->taps = g.taps;
@@ -425,6 +437,7 @@ struct multi_params {
   int tiles_x, tiles_y;
   int band_shift, band_count, band_index;
   int hdr, hdr_low, hdr_high;
+  const eu_generic *gen;
 };
 
 // fuse() for several facets (envutil_payload.cc:2139-2180, :2240-2281): one
@@ -492,8 +505,29 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
     g.msrc_cap = (size_t)nsrc;
   }
   HIPCHK(hipMemcpyAsync(g.msrc, sd.data(), sizeof(eu_src_dev) * (size_t)nsrc, hipMemcpyHostToDevice, g.stream));
+  // facets with translation parameters step through generic_stepper (envutil_payload.cc:2145-2158,
+  // :2246-2258); like the evaluator parameters these are refreshed on every job
+  std::vector<eu_generic> gv((size_t)nsrc);
+  bool any_generic = false;
+  for (int f = 0; f < nsrc; f++) {
+    memset(&gv[f], 0, sizeof(eu_generic));
+    if (!eu::has_translation(srcs[f]->fct)) continue;
+    if (!eu::make_generic(*t, srcs[f]->fct, gv[f]))
+      return fail(EU_ERR_UNSUPPORTED, "translated facet: no planar-to-ray functor for this target projection");
+    any_generic = true;
+  }
+  if (any_generic) {
+    if (g.mgen_cap < (size_t)nsrc) {
+      if (g.mgen) (void)hipFree(g.mgen);
+      g.mgen = nullptr; g.mgen_cap = 0;
+      HIPCHK(hipMalloc((void **)&g.mgen, sizeof(eu_generic) * (size_t)nsrc));
+      g.mgen_cap = (size_t)nsrc;
+    }
+    HIPCHK(hipMemcpyAsync(g.mgen, gv.data(), sizeof(eu_generic) * (size_t)nsrc, hipMemcpyHostToDevice, g.stream));
+  }
   HIPCHK(hipStreamSynchronize(g.stream));
   memset(p, 0, sizeof *p);
+  p->gen = any_generic ? g.mgen : nullptr;
   p->width = frame_w(t); p->height = frame_h(t); p->row_begin = t->row_begin; p->row_end = t->row_end;
   if (t->band_count > 1) {
     p->band_shift = band_shift_of(t->band_rows); p->band_count = t->band_count; p->band_index = t->band_index;

@@ -13,7 +13,8 @@
 enum { EU_FORM_BCA = 0,      // (B*c0 + C*c1) + A   spherical, cylindrical
        EU_FORM_BA = 1,       //  B*c0 + A           rectilinear, cubemap, biatan6
        EU_FORM_FISH = 2,     //  per-pixel polar form of the fisheye stepper
-       EU_FORM_STER = 3 };   //  the same with the stereographic latitude
+       EU_FORM_STER = 3,     //  the same with the stereographic latitude
+       EU_FORM_GENERIC = 4 };//  generic_stepper over tf_ex_facet (a facet with translation): eu_generic
                              //  (c0 = planar x, row: xx, yy, zz, planar y)
 enum { EU_NORM_NONE = 0, EU_NORM_DIV = 1, EU_NORM_CYL = 2 };
 
@@ -68,11 +69,21 @@ inline int eu_frame_row(int yl, int shift, int count, int index)
   return ((((yl >> shift) * count) + index) << shift) | (yl & ((1 << shift) - 1));
 }
 
+// generic_stepper (stepper.h:353-490) over tf_ex_facet (envutil_payload.cc:1841-1885) for a facet with
+// PTO translation parameters: planar -> ray by the TARGET's projection (roll_out_23, geometry.h:
+// 1800-1837) -> tf3d_t (geometry.h:1850-1941). Matrices are r3_t<float>, m[3 * i + c] = r[i][c].
+struct eu_generic {
+  int on, prj, has_shift;
+  float dcp;
+  float shift[3];
+  float trg_to_md[9], md_to_src[9], trg_to_src[9];
+};
+
 struct eu_render_params {
   int width, height, row_begin, row_end;
   int form, norm_mode, twine, ntaps, stage, nch;   // nch: channels of the source
   int nch_out;               // channels of the target (repix_t when they differ)
-  const float *col;          // [4][width]: c0, c1, c0 (x-biased), c1 (x-biased)
+  const float *col;          // [6][width]: c0, c1, c0 (x-biased), c1 (x-biased), planar x, planar x (x-biased)
   const float *row;          // [height][EU_ROW_FLOATS]
   const float *taps;         // [ntaps][3], x and y already scaled by 4
   float *out;
@@ -88,6 +99,7 @@ struct eu_render_params {
   int layout;                // packed kernel: 0 by environment (default row strips), 1 row strips,
                              // 2 32x16 tiles with direct gathers (eu_render2.hip)
   eu_src_dev src;
+  eu_generic gen;            // form == EU_FORM_GENERIC
 };
 
 #endif

@@ -520,12 +520,56 @@ __device__ __forceinline__ float eu_norm3(float x, float y, float z)
   return sqrtf(sqn);
 }
 
-// full stepper: tables -> ray, with the normalisation flavour of the stepper
+// rotate(xel_t<float,3>, r3_t<float>), geometry.h:80-87
+__device__ __forceinline__ void eu_rotate3(const float *m, float x, float y, float z, float &ox,
+                                           float &oy, float &oz)
+{
+  const float a = x * m[0] + y * m[3], b = x * m[1] + y * m[4], c = x * m[2] + y * m[5];
+  ox = a + z * m[6]; oy = b + z * m[7]; oz = c + z * m[8];
+}
+
+// generic_stepper's tf (tf_ex_facet::eval, envutil_payload.cc:1869-1884): planar -> ray by the target's
+// projection (geometry.h: ll_to_ray_t :152-211, cyl_to_ray_t :417-446, rect_to_ray_t :363-387,
+// ster_to_ray_t :481-510, fish_to_ray_t :539-566), then tf3d_t::eval (:1896-1941; its all_of / any_of
+// tests only skip work)
+__device__ __forceinline__ void eu_generic_ray(const eu_generic &g, float p0, float p1, float &rx,
+                                               float &ry, float &rz)
+{
+  float x, y, z;
+  if (g.prj == EU_SPHERICAL) {
+    const float sinlat = eu_sinf(p1), coslat = eu_cosf(p1), sinlon = eu_sinf(p0), coslon = eu_cosf(p0);
+    x = sinlon * coslat; z = coslon * coslat; y = sinlat;
+  } else if (g.prj == EU_CYLINDRICAL) {
+    z = eu_cosf(p0); x = eu_sinf(p0); y = p1;
+  } else if (g.prj == EU_RECTILINEAR) {
+    x = p0; y = p1; z = 1.0f;
+  } else {
+    const float r = sqrtf(p0 * p0 + p1 * p1);
+    const float theta = g.prj == EU_STEREOGRAPHIC ? eu_atanf(r / 2.0f) * 2.0f : r;
+    const float phi = eu_atan2f(p0, -p1);
+    const float st = eu_sinf(theta);
+    z = eu_cosf(theta); y = -st * eu_cosf(phi); x = st * eu_sinf(phi);
+  }
+  if (!g.has_shift) { eu_rotate3(g.trg_to_src, x, y, z, rx, ry, rz); return; }
+  float tx, ty, tz;
+  eu_rotate3(g.trg_to_md, x, y, z, tx, ty, tz);
+  const bool mask = tz <= 0.0f;
+  tx = tx / tz; ty = ty / tz; tz = 1.0f;
+  tx = tx * g.dcp; ty = ty * g.dcp; tz = tz * g.dcp;
+  tx = tx - g.shift[0]; ty = ty - g.shift[1]; tz = tz - g.shift[2];
+  eu_rotate3(g.md_to_src, tx, ty, tz, rx, ry, rz);
+  if (mask) { rx = 0.0f; ry = 0.0f; rz = -__builtin_huge_valf(); }
+}
+
+// full stepper: tables -> ray, with the normalisation flavour of the stepper. gen / raw: the facet's
+// eu_generic and the raw planar x column, for form == EU_FORM_GENERIC
 __device__ __forceinline__ void eu_stepper(int form, int norm_mode, const float *colA,
                                            const float *colB, const float *rowt, int x,
-                                           float &rx, float &ry, float &rz)
+                                           float &rx, float &ry, float &rz,
+                                           const eu_generic *gen = nullptr, const float *raw = nullptr)
 {
-  eu_ray(form, rowt, colA[x], colB[x], rx, ry, rz);
+  if (form == EU_FORM_GENERIC) eu_generic_ray(*gen, raw[x], rowt[9], rx, ry, rz);
+  else eu_ray(form, rowt, colA[x], colB[x], rx, ry, rz);
   if (norm_mode == EU_NORM_DIV) {
     float n = eu_norm3(rx, ry, rz);
     rx = rx / n; ry = ry / n; rz = rz / n;
@@ -571,7 +615,9 @@ __device__ __forceinline__ void eu_stepper(const eu_render_params &p, const floa
                                            const float *colB, const float *rowt, int x,
                                            float &rx, float &ry, float &rz)
 {
-  eu_stepper(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz);
+  // colA is p.col (r00, r01) or p.col + 2 * width (r10): the raw planar column goes with it
+  const float *raw = p.col + (colA == p.col ? 4 : 5) * (long long)p.width;
+  eu_stepper(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz, &p.gen, raw);
 }
 
 #endif

@@ -38,6 +38,7 @@ struct eu_multi_params {
   int tiles_x, tiles_y;
   int band_shift, band_count, band_index;   // eu_frame_row
   int hdr, hdr_low, hdr_high;               // _hdr_merge_syn: the facets that rule the shadows / the highlights
+  const eu_generic *gen;                    // [nfct] or nullptr: facets stepped by generic_stepper (translation)
 };
 
 struct eu_pix { int x, y; };
@@ -49,6 +50,12 @@ __device__ __forceinline__ void eu_multi_ray(const eu_multi_params &p, int f, in
   const float *rowt = p.row + ((long long)f * p.height + eu_frame_row(px.y, p.band_shift, p.band_count, p.band_index)) * EU_ROW_FLOATS
                       + (variant == 2 ? EU_ROW_VARIANT : 0);
   const float *ca = variant == 1 ? p.col + 2 * p.width : p.col;
+  if (p.gen && p.gen[f].on) {               // f is wave-uniform
+    // generic_stepper<float, LANES, true>: the ray is normalised (stepper.h:431-434)
+    eu_stepper(EU_FORM_GENERIC, EU_NORM_DIV, ca, ca, rowt, px.x, rx, ry, rz, &p.gen[f],
+               p.col + (variant == 1 ? 5 : 4) * (long long)p.width);
+    return;
+  }
   eu_stepper(p.form, p.norm_mode, ca, ca + p.width, rowt, px.x, rx, ry, rz);
 }
 

@@ -390,11 +390,16 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
   const float a0 = (float)t.x0, a1 = (float)t.x1, b0 = (float)t.y0, b1 = (float)t.y1;
   float xx[3], yy[3], zz[3];
   for (int i = 0; i < 3; i++) { xx[i] = (float)basis.m[i]; yy[i] = (float)basis.m[3 + i]; zz[i] = (float)basis.m[6 + i]; }
-  tb.col.assign((size_t)4 * OW, 0.0f);
+  tb.col.assign((size_t)6 * OW, 0.0f);
   tb.row.assign((size_t)OH * EU_ROW_FLOATS, 0.0f);
   std::vector<float> p0((size_t)OW), p0b((size_t)OW);
   planar_columns(W, a0, a1, 0.0f, p0.data(), X0, OW);
   if (twine) planar_columns(W, a0, a1, 0.25f, p0b.data(), X0, OW);
+  // the raw planar x of every column (generic_stepper facets, eu_generic)
+  for (int x = 0; x < OW; x++) {
+    tb.col[(size_t)4 * OW + x] = p0[x];
+    if (twine) tb.col[(size_t)5 * OW + x] = p0b[x];
+  }
   const float section_md = a1 - a0, refc_md = (float)((a1 - a0) / 2.0);
   const float q = (float)(M_PI / 4.0);
   tb.norm_mode = EU_NORM_NONE;
@@ -485,6 +490,65 @@ inline bool build_stepper_tables(const eu_target &t, const mat3 &basis, bool nor
       }
     }
   }
+  return true;
+}
+
+// generic_r3(ft, fs) for ft = the job's target (no translation of its own), envutil_payload.cc:
+// 1757-1810: the facet's tf3d_t. Float matrix products as rotate(r3_t<float>, r3_t<float>)
+// (geometry.h:80-97) forms them. false: target projections whose planar -> ray functor
+// (ir_to_ray_t, ba6_to_ray_t) is not built.
+inline void r3f(double roll, double pitch, double yaw, bool inverse, float *m)
+{
+  const mat3 d = make_r3(roll, pitch, yaw, inverse);
+  for (int i = 0; i < 9; i++) m[i] = (float)d.m[i];
+}
+inline void rotate_f(const float *in, const float *m, float *out)
+{
+  float t[3];
+  for (int c = 0; c < 3; c++) { float v = in[0] * m[c] + in[1] * m[3 + c]; t[c] = v + in[2] * m[6 + c]; }
+  out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+}
+inline void rotate_mf(const float *l, const float *r, float *o)
+{
+  float t[9];
+  for (int i = 0; i < 3; i++) rotate_f(l + 3 * i, r, t + 3 * i);
+  std::memcpy(o, t, sizeof t);
+}
+inline bool has_translation(const eu_facet &f) { return f.tr_x != 0 || f.tr_y != 0 || f.tr_z != 0; }
+
+inline bool make_generic(const eu_target &t, const eu_facet &f, eu_generic &g)
+{
+  std::memset(&g, 0, sizeof g);
+  switch (t.projection) {
+    case EU_SPHERICAL: case EU_CYLINDRICAL: case EU_RECTILINEAR: case EU_STEREOGRAPHIC: case EU_FISHEYE: break;
+    default: return false;
+  }
+  float r_camera[9], rs_tp[9], rs_tpi[9], r_facet[9];
+  r3f(t.roll, t.pitch, t.yaw, false, r_camera);
+  r3f(f.tp_r, f.tp_p, f.tp_y, true, rs_tp);
+  r3f(f.tp_r, f.tp_p, f.tp_y, false, rs_tpi);
+  r3f(f.roll, f.pitch, f.yaw, true, r_facet);
+  float sh[3] = { (float)f.tr_x, (float)f.tr_y, (float)f.tr_z };
+  if (f.tp_y != 0 || f.tp_p != 0 || f.tp_r != 0) {
+    // rotate(xel_t<double,3>(shift_s), rs_tp): double vector, float matrix, narrowed on assignment
+    const double v[3] = { sh[0], sh[1], sh[2] };
+    for (int c = 0; c < 3; c++)
+      sh[c] = (float)((v[0] * (double)rs_tp[c] + v[1] * (double)rs_tp[3 + c]) + v[2] * (double)rs_tp[6 + c]);
+  }
+  if (has_translation(f)) {
+    rotate_mf(r_camera, rs_tp, g.trg_to_md);
+    rotate_mf(rs_tpi, r_facet, g.md_to_src);
+    rotate_mf(g.trg_to_md, g.md_to_src, g.trg_to_src);
+    for (int c = 0; c < 3; c++) g.shift[c] = sh[c];
+  } else {
+    std::memcpy(g.trg_to_md, r_camera, sizeof r_camera);
+    std::memcpy(g.md_to_src, r_facet, sizeof r_facet);
+    rotate_mf(r_camera, r_facet, g.trg_to_src);
+  }
+  g.dcp = 1.0f;
+  g.has_shift = g.shift[0] != 0 || g.shift[1] != 0 || g.shift[2] != 0;
+  g.prj = t.projection;
+  g.on = 1;
   return true;
 }
 

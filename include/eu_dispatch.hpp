@@ -174,6 +174,8 @@ struct hip_dispatch : public dispatch_base
     e.brighten = f.brighten; e.step = f.step; e.has_lcp = f.has_lcp;
     e.a = f.a; e.b = f.b; e.c = f.c; e.h = f.h; e.v = f.v; e.s = f.s;
     e.shear_g = f.shear_g; e.shear_t = f.shear_t;
+    // PTO translation: such a facet is stepped by generic_stepper (envutil_payload.cc:2095-2110, :2145-2158)
+    e.tr_x = f.tr_x; e.tr_y = f.tr_y; e.tr_z = f.tr_z; e.tp_y = f.tp_y; e.tp_p = f.tp_p; e.tp_r = f.tp_r;
     return e;
   }
 
@@ -182,15 +184,13 @@ struct hip_dispatch : public dispatch_base
     if (projection != args.projection) return EU_ERR_ARGUMENT;
     if ((ninputs == 9) != !args.twine_spread.empty()) return EU_ERR_ARGUMENT;
     if (args.tethered ? !args.p_screen_data : !args.p_output) return EU_ERR_ARGUMENT;
-    // outside this path: unstitching, masks, lens crops, translated facets - the
+    // outside this path: unstitching, masks, lens crops - the
     // reference's CPU dispatch keeps them; an unknown synopsis is the reference's assert(false)
     // (envutil_payload.cc:2316-2318)
     if (args.synopsis != "panorama" && args.synopsis != "hdr_merge") return EU_ERR_ARGUMENT;
     if (args.single >= 0 || !args.split.empty()) return EU_ERR_UNSUPPORTED;
     for (const auto &fct : args.facet_spec_v)
-      if (fct.has_pto_mask || fct.has_lens_crop || fct.masked != -1 || fct.tr_x != 0.0 || fct.tr_y != 0.0 ||
-          fct.tr_z != 0.0 || fct.tp_y != 0.0 || fct.tp_p != 0.0 || fct.tp_r != 0.0)
-        return EU_ERR_UNSUPPORTED;
+      if (fct.has_pto_mask || fct.has_lens_crop || fct.masked != -1) return EU_ERR_UNSUPPORTED;
     std::vector<eu_source *> srcs;
     for (const auto &fct : args.facet_spec_v) {
       auto it = resident.find(fct.asset_key);

@@ -72,6 +72,11 @@ typedef struct eu_facet {
   double  step;                  /* facet_base::step (get_step)                */
   int32_t has_lcp;               /* lens polynomial / shift / shear present    */
   double  a, b, c, h, v, s, shear_g, shear_t;
+  /* PTO translation (facet_base::tr_*, tp_*, envutil_basic.h:446-447): position of the virtual camera
+   * in model space units and the orientation of the translation plane (radians). A facet with
+   * tr_x/y/z != 0 is stepped by generic_stepper over tf_ex_facet (envutil_payload.cc:2095-2110,
+   * :2145-2158; geometry.h:1850-1941) instead of the target projection's own stepper.            */
+  double  tr_x, tr_y, tr_z, tp_y, tp_p, tp_r;
 } eu_facet;
 
 typedef struct eu_source eu_source;   /* opaque: coefficients resident in HBM */

@@ -1037,7 +1037,135 @@ typedef struct {
   float xx[3], yy[3], zz[3];
   float section_md, refc_md;     /* cubemap/biatan6 */
   int x_off, y_off;              /* bill.get_offset (wielding.h:215-224)   */
+  /* generic_stepper (stepper.h:353-490) over tf_ex_facet (envutil_payload.cc:1841-1885): used for
+   * a facet with translation parameters. tf33 = generic_r3, a tf3d_t (geometry.h:1850-1941) */
+  int generic, has_shift;
+  float trg_to_md[9], md_to_src[9], trg_to_src[9], shift[3], dcp;   /* r3_t<float>: m[3 * i + c] = r[i][c] */
 } stepper_t;
+
+/* rotate(xel_t<U,3>, r3_t<T>), geometry.h:80-87: (lhs[0] * rhs[0]) + (lhs[1] * rhs[1]) + (lhs[2] * rhs[2]) */
+static void rotate_f(const float *in, const float *m, float *out)
+{
+  float t[3];
+  for (int c = 0; c < 3; c++) {
+    float v = in[0] * m[c] + in[1] * m[3 + c];
+    t[c] = v + in[2] * m[6 + c];
+  }
+  out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+}
+static void rotate_m_f(const float *lhs, const float *rhs, float *out9)   /* r3_t<float> x r3_t<float> */
+{
+  float t[9];
+  for (int i = 0; i < 3; i++) rotate_f(lhs + 3 * i, rhs, t + 3 * i);
+  memcpy(out9, t, sizeof t);
+}
+static void make_r3_f(double roll, double pitch, double yaw, int inverse, float *m9)
+{
+  double d[9];
+  euo_make_r3(roll, pitch, yaw, inverse, d);     /* r3_t<double> narrowed into r3_t<float> */
+  for (int i = 0; i < 9; i++) m9[i] = (float)d[i];
+}
+
+/* generic_r3(ft, fs), envutil_payload.cc:1636-1755: ft the target in camera position, fs the source
+ * facet; ft6/fs6 = { tr_x, tr_y, tr_z, tp_y, tp_p, tp_r } */
+static void generic_r3_init(stepper_t *s, const double *ft_rpy, const double *ft6, const double *fs_rpy,
+                            const double *fs6)
+{
+  float r_camera[9], rt_tp[9], rt_tpi[9], rs_tp[9], rs_tpi[9], r_facet[9];
+  make_r3_f(ft_rpy[0], ft_rpy[1], ft_rpy[2], 0, r_camera);
+  make_r3_f(ft6[5], ft6[4], ft6[3], 1, rt_tp);
+  make_r3_f(ft6[5], ft6[4], ft6[3], 0, rt_tpi);
+  make_r3_f(fs6[5], fs6[4], fs6[3], 1, rs_tp);
+  make_r3_f(fs6[5], fs6[4], fs6[3], 0, rs_tpi);
+  make_r3_f(fs_rpy[0], fs_rpy[1], fs_rpy[2], 1, r_facet);
+  int have_ttp = ft6[0] != 0 || ft6[1] != 0 || ft6[2] != 0;
+  int have_stp = fs6[0] != 0 || fs6[1] != 0 || fs6[2] != 0;
+  float shift_t[3] = { (float)ft6[0], (float)ft6[1], (float)ft6[2] };
+  if (ft6[3] != 0 || ft6[4] != 0 || ft6[5] != 0) {
+    /* rotate(xel_t<double,3>(shift_t), rt_tp): double vector, float matrix, narrowed on assignment */
+    double v[3] = { shift_t[0], shift_t[1], shift_t[2] }, o[3];
+    for (int c = 0; c < 3; c++) o[c] = (v[0] * (double)rt_tp[c] + v[1] * (double)rt_tp[3 + c]) + v[2] * (double)rt_tp[6 + c];
+    for (int c = 0; c < 3; c++) shift_t[c] = (float)o[c];
+  }
+  float dcp = (float)(1.0 - (double)shift_t[2]);
+  for (int c = 0; c < 3; c++) shift_t[c] = -shift_t[c];
+  float shift_s[3] = { (float)fs6[0], (float)fs6[1], (float)fs6[2] };
+  if (fs6[3] != 0 || fs6[4] != 0 || fs6[5] != 0) {
+    double v[3] = { shift_s[0], shift_s[1], shift_s[2] }, o[3];
+    for (int c = 0; c < 3; c++) o[c] = (v[0] * (double)rs_tp[c] + v[1] * (double)rs_tp[3 + c]) + v[2] * (double)rs_tp[6 + c];
+    for (int c = 0; c < 3; c++) shift_s[c] = (float)o[c];
+  }
+  const float *sh = NULL;
+  s->dcp = 1.0f;
+  if (have_ttp && have_stp) {
+    s->generic = 2;              /* tf3d1 + tf3d2: two chained tf3d_t - not restated (only --single reaches it) */
+    return;
+  } else if (have_ttp) {
+    rotate_m_f(r_camera, rt_tp, s->trg_to_md);
+    rotate_m_f(rt_tpi, r_facet, s->md_to_src);
+    sh = shift_t; s->dcp = dcp;
+  } else if (have_stp) {
+    rotate_m_f(r_camera, rs_tp, s->trg_to_md);
+    rotate_m_f(rs_tpi, r_facet, s->md_to_src);
+    sh = shift_s;
+  } else {
+    float id[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    memcpy(s->trg_to_md, r_camera, sizeof id);
+    memcpy(s->md_to_src, r_facet, sizeof id);
+  }
+  rotate_m_f(s->trg_to_md, s->md_to_src, s->trg_to_src);
+  if (!have_ttp && !have_stp) rotate_m_f(r_camera, r_facet, s->trg_to_src);   /* rotate_t(r_complete) */
+  s->shift[0] = s->shift[1] = s->shift[2] = 0.0f;
+  if (sh) { s->shift[0] = sh[0]; s->shift[1] = sh[1]; s->shift[2] = sh[2]; }
+  s->has_shift = s->shift[0] != 0 || s->shift[1] != 0 || s->shift[2] != 0;
+  s->generic = 1;
+}
+
+/* roll_out_23 (geometry.h:1800-1837): planar -> ray by the target's projection, float */
+static int planar_to_ray_f(int projection, const float *in, float *out)
+{
+  switch (projection) {
+    case EUO_SPHERICAL: {        /* ll_to_ray_t, geometry.h:152-211 */
+      float sinlat = sinf(in[1]), coslat = cosf(in[1]), sinlon = sinf(in[0]), coslon = cosf(in[0]);
+      out[0] = sinlon * coslat; out[2] = coslon * coslat; out[1] = sinlat;
+      return 1;
+    }
+    case EUO_CYLINDRICAL:        /* cyl_to_ray_t, geometry.h:417-446 */
+      out[2] = cosf(in[0]); out[0] = sinf(in[0]); out[1] = in[1];
+      return 1;
+    case EUO_RECTILINEAR:        /* rect_to_ray_t, geometry.h:363-387 */
+      out[0] = in[0]; out[1] = in[1]; out[2] = 1.0f;
+      return 1;
+    case EUO_STEREOGRAPHIC: {    /* ster_to_ray_t, geometry.h:481-510 */
+      float r = sqrtf(in[0] * in[0] + in[1] * in[1]);
+      float theta = atanf(r / 2.0f) * 2.0f;
+      float phi = atan2f(in[0], -in[1]);
+      out[2] = cosf(theta); out[1] = -sinf(theta) * cosf(phi); out[0] = sinf(theta) * sinf(phi);
+      return 1;
+    }
+    case EUO_FISHEYE: {          /* fish_to_ray_t, geometry.h:539-566 */
+      float r = sqrtf(in[0] * in[0] + in[1] * in[1]);
+      float phi = atan2f(in[0], -in[1]);
+      out[2] = cosf(r); out[1] = -sinf(r) * cosf(phi); out[0] = sinf(r) * sinf(phi);
+      return 1;
+    }
+  }
+  return 0;                      /* ir_to_ray_t / ba6_to_ray_t: not restated */
+}
+
+/* tf3d_t::eval, geometry.h:1896-1941; the all_of / any_of tests only skip work */
+static void tf3d_eval(const stepper_t *s, const float *in, float *out)
+{
+  if (!s->has_shift) { rotate_f(in, s->trg_to_src, out); return; }
+  float t[3];
+  rotate_f(in, s->trg_to_md, t);
+  int mask = t[2] <= 0.0f;
+  t[0] /= t[2]; t[1] /= t[2]; t[2] = 1.0f;
+  for (int c = 0; c < 3; c++) t[c] *= s->dcp;
+  for (int c = 0; c < 3; c++) t[c] -= s->shift[c];
+  rotate_f(t, s->md_to_src, out);
+  if (mask) { out[0] = 0.0f; out[1] = 0.0f; out[2] = -INFINITY; }
+}
 
 /* stepper.h:294-307 */
 static void stepper_init(stepper_t *s, int projection, int normalize,
@@ -1065,7 +1193,22 @@ static void stepper_init(stepper_t *s, int projection, int normalize,
   s->section_md = a1 - a0;
   s->refc_md = (float)((a1 - a0) / 2.0);
   s->x_off = s->y_off = 0;
+  s->generic = 0;
 }
+
+/* fuse() (envutil_payload.cc:2095-2110, :2145-2158): a facet with translation parameters gets
+ * generic_stepper(tf_ex_facet(args, fct)); returns 0 when this build does not restate the case */
+static int stepper_make_generic(stepper_t *s, const euo_job *job, const euo_source *src)
+{
+  double ft_rpy[3] = { job->roll, job->pitch, job->yaw }, ft6[6] = { 0, 0, 0, 0, 0, 0 };
+  double fs_rpy[3] = { src->roll, src->pitch, src->yaw };
+  double fs6[6] = { src->tr_x, src->tr_y, src->tr_z, src->tp_y, src->tp_p, src->tp_r };
+  float probe[2] = { 0.0f, 0.0f }, r[3];
+  if (!planar_to_ray_f(s->projection, probe, r)) return 0;
+  generic_r3_init(s, ft_rpy, ft6, fs_rpy, fs6);
+  return s->generic == 1;
+}
+static int has_translation(const euo_source *src) { return src->tr_x != 0 || src->tr_y != 0 || src->tr_z != 0; }
 
 /* planar coordinate of pixel (x, y): stepper.h:324-350. The x value is the
  * segment-start value of the pixel's lane plus k additions of delta. */
@@ -1100,6 +1243,13 @@ static void stepper_ray(const stepper_t *s, int x, int y, float *trg)
 {
   float pl[2];
   planar_at(s, x, y, pl);
+  if (s->generic) {             /* generic_stepper::init / increase, stepper.h:422-473 */
+    float r[3];
+    planar_to_ray_f(s->projection, pl, r);
+    tf3d_eval(s, r, trg);
+    if (s->normalize) normalize3(trg);
+    return;
+  }
   const float *xx = s->xx, *yy = s->yy, *zz = s->zz;
   switch (s->projection) {
     case EUO_SPHERICAL: {       /* stepper.h:605-667 */
@@ -1709,6 +1859,9 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
     stepper_init(&st[3 * f + 2], job->projection, 1, basis, job->width, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.25f);
     if (job->crop_w > 0)
       for (int v = 0; v < 3; v++) { st[3 * f + v].x_off = job->crop_x0; st[3 * f + v].y_off = job->crop_y0; }
+    if (has_translation(&srcs[f]))
+      for (int v = 0; v < 3; v++)
+        if (!stepper_make_generic(&st[3 * f + v], job, &srcs[f])) { free(sy); free(st); return -4; }
     mount_init(&sy->mnt[f], &srcs[f]);
     sy->recip_step[f] = (float)(1.0 / srcs[f].step);
     sy->optimum[f] = 0.5f * (float)srcs[f].brighten;
@@ -1819,6 +1972,11 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
   if (job->crop_w > 0) {
     st00.x_off = st10.x_off = st01.x_off = job->crop_x0;
     st00.y_off = st10.y_off = st01.y_off = job->crop_y0;
+  }
+  if (has_translation(src)) {
+    /* generic_stepper<float, LANES, false> / deriv_stepper<..., generic_stepper, true> (payload.cc:2095-2110, :2214-2224) */
+    if (!stepper_make_generic(&st00, job, src) || !stepper_make_generic(&st10, job, src) ||
+        !stepper_make_generic(&st01, job, src)) return -4;
   }
   float lut[257];
   euo_screen_lut(lut);

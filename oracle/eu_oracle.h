@@ -63,6 +63,9 @@ typedef struct {
   double step;
   int has_lcp;                 /* lens polynomial + shift + shear present */
   double a, b, c, h, v, s, shear_g, shear_t;
+  /* PTO translation (facet_base, envutil_basic.h:446-447): position of the virtual camera in model
+   * space units, orientation of the translation plane (radians) */
+  double tr_x, tr_y, tr_z, tp_y, tp_p, tp_r;
   euo_spline spl;
   /* cubemap sources: cubemap_view_t members, environment.h:1425-1436 */
   float refc_md, model_to_px;

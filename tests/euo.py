@@ -33,6 +33,8 @@ class Source(C.Structure):
                 ("a", C.c_double), ("b", C.c_double), ("c", C.c_double),
                 ("h", C.c_double), ("v", C.c_double), ("s", C.c_double),
                 ("shear_g", C.c_double), ("shear_t", C.c_double),
+                ("tr_x", C.c_double), ("tr_y", C.c_double), ("tr_z", C.c_double),
+                ("tp_y", C.c_double), ("tp_p", C.c_double), ("tp_r", C.c_double),
                 ("spl", Spline),
                 ("refc_md", C.c_float), ("model_to_px", C.c_float),
                 ("section_px", C.c_int)]

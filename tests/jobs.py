@@ -45,7 +45,7 @@ class OracleSource:
 
     def __init__(self, prj, width, height, hfov_deg, pixels, spline_degree,
                  prefilter_degree=None, yaw=0.0, pitch=0.0, roll=0.0, brighten=1.0,
-                 support_min=8, tile=64, lens=None, window=None):
+                 support_min=8, tile=64, lens=None, window=None, translation=None):
         """window = (window_width, window_height, x_offset, y_offset): `pixels` is that
         window of a width x height frame (a cropped PTO image, envutil_basic.h:447-470)"""
         if prefilter_degree is None:
@@ -68,6 +68,10 @@ class OracleSource:
             for k, v in lens.items():
                 setattr(s, {"g": "shear_g", "t": "shear_t"}.get(k, k), v)
             s.has_lcp = int(any(lens.get(k, 0.0) != 0.0 for k in "abc"))
+        if translation:
+            # PTO TrX, TrY, TrZ (model space units) and the translation plane's Tpy, Tpp (+ roll), degrees
+            s.tr_x, s.tr_y, s.tr_z = (translation.get(k, 0.0) for k in ("x", "y", "z"))
+            s.tp_y, s.tp_p, s.tp_r = (math.radians(translation.get(k, 0.0)) for k in ("tp_y", "tp_p", "tp_r"))
         if prj in (euo.CUBEMAP, euo.BIATAN6):
             m, ir = euo.cubemap_build(pixels, spline_degree, prefilter_degree, hf,
                                       support_min, tile)

@@ -260,3 +260,31 @@ def test_hdr_merge_command_line_to_pixels(demo, tmp_path):
                              brighten=br[k]) for k in range(3)]
     a = ea.arguments(ea.RECTILINEAR, 240, 160, 80.0, spline_degree=1, synopsis="hdr_merge")
     assert fnv1a(jobs.oracle_render(a, os_)) == got
+
+
+@pytest.mark.gpu
+def test_pto_mosaic_with_translation_to_pixels(demo, tmp_path):
+    """TrX/TrY/TrZ/Tpy/Tpp of a PTO image line reach the kernel: front end -> payload() -> generic_stepper
+    on the device == the oracle"""
+    import euo
+    import jobs
+    from test_cpp_dispatch import fnv1a
+    (tmp_path / "mosaic.pto").write_text(
+        'p f0 w260 h180 v90 n"TIFF"\n'
+        'i w200 h150 f0 v60 y-10 p0 r0 n"a.tif"\n'
+        'i w200 h150 f0 v60 y12 p2 r1 TrX0.2 TrY-0.05 TrZ0.1 Tpy5 Tpp-3 n"b.tif"\n')
+    j, tail = demo(["--pto", "mosaic.pto", "--output", "o.tif", "--degree", "1", "--twine", "0"],
+                   {"a.tif": (200, 150, 3), "b.tif": (200, 150, 3)}, cwd=str(tmp_path), render=True)
+    assert j["ok"] and "rc 0" in tail, tail
+    assert j["facets"][1]["tr"] == [0.2, -0.05, -0.1]          # TrZ changes sign, envutil_main.cc:788
+    got = tail.split("fnv1a")[1].strip()
+
+    def pixels(k, w, h, n):
+        y, x, c = np.indices((h, w, n))
+        return (np.float32(0.5) + np.float32(0.25) * ((x * 7 + y * 13 + c * 29 + k * 5) % 97).astype(np.float32)
+                / np.float32(97.0)).astype(np.float32)
+    o0 = jobs.OracleSource(euo.RECTILINEAR, 200, 150, 60.0, pixels(0, 200, 150, 3), 1, yaw=-10.0)
+    o1 = jobs.OracleSource(euo.RECTILINEAR, 200, 150, 60.0, pixels(1, 200, 150, 3), 1, yaw=12.0, pitch=2.0, roll=1.0,
+                           translation=dict(x=0.2, y=-0.05, z=-0.1, tp_y=5.0, tp_p=-3.0))
+    a = ea.arguments(ea.RECTILINEAR, 260, 180, 90.0, spline_degree=1)
+    assert fnv1a(jobs.oracle_render(a, [o0, o1])) == got
