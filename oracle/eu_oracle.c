@@ -1027,6 +1027,108 @@ void euo_cubemap_build(const euo_metrics *m, const float *faces, int nch,
 }
 
 /* ------------------------------------------------------------------------ */
+/* inverse_lcp (lens_correction.h:236-301): the inverse of the PTO radial     */
+/* factor as a cubic b-spline over sqrt-spaced knots, built by Newton          */
+/* iteration in double (eu_polynomial::inverse, :112-139). Pinned against the  */
+/* reference's own class through oracle/ref_zimt.cc (ref_inverse_lcp).         */
+/* ------------------------------------------------------------------------ */
+
+#define EUO_INV_LCP_MAX 136
+typedef struct {
+  int nk;
+  long left;
+  double rr_max;
+  float coef[EUO_INV_LCP_MAX];   /* braced, prefiltered; core starts at coef[left] */
+  float m[16];                   /* weight matrix, degree 3 */
+} inv_lcp_t;
+
+static double poly4_function(const double *cf, double x)
+{
+  double sum = 0.0, power = 1.0;
+  for (int i = 0; i <= 4; i++) { sum += cf[4 - i] * power; power *= x; }
+  return sum;
+}
+static double poly4_derivative(const double *dcf, double x)
+{
+  double sum = 0.0, power = 1.0;
+  for (int i = 0; i < 4; i++) { sum += dcf[4 - i - 1] * power; power *= x; }
+  return sum;
+}
+
+static int inv_lcp_init(inv_lcp_t *q, double a, double b, double c, double r_max_in, int sz)
+{
+  double cf[5] = { a, b, c, 1.0 - (a + b + c), 0.0 }, dcf[5];
+  { int power = 4; for (int i = 0; i <= 4; i++) { dcf[i] = cf[i] * power; --power; } }
+  int nk = sz + 4;
+  long left = left_brace(3, EUO_NATURAL), right = right_brace(3, EUO_NATURAL);
+  if (nk + left + right > EUO_INV_LCP_MAX) return 0;
+  double r_max = r_max_in * ((sz + 3.0) / sz);
+  q->rr_max = poly4_function(cf, r_max);
+  q->nk = nk;
+  q->left = left;
+  float *core = q->coef + left;
+  for (int i = 0; i < nk; i++) {
+    double notch = (double)i / (nk - 1);
+    notch *= notch;
+    notch *= q->rr_max;
+    double out = i * r_max / sz;
+    {                                           /* eu_polynomial::inverse, tolerance 100 eps */
+      const double tolerance = 100 * DBL_EPSILON;
+      double current = out, result, difference = 0.0, last_difference = DBL_MAX;
+      for (int count = 0; count < 16; count++) {
+        result = poly4_function(cf, current);
+        difference = notch - result;
+        if (last_difference == difference) break;
+        if (fabs(difference) <= tolerance) break;
+        last_difference = difference;
+        current = current + difference / poly4_derivative(dcf, current);
+      }
+      if (fabs(difference) < tolerance) out = current;
+    }
+    core[i] = (float)(notch == 0.0 ? 1.0 / poly4_derivative(dcf, 0.0) : (out / notch) - 1);
+  }
+  /* bspline<float,1>::prefilter: one line, then the NATURAL brace (point mirror, brace.h:134+) */
+  euo_filter_lines(core, 1, nk, nk, 1, EUO_NATURAL, 3, FLT_EPSILON);
+  for (long k = 1; k <= left; k++) core[-k] = core[0] + core[0] - core[k];
+  for (long k = 1; k <= right; k++) core[nk - 1 + k] = core[nk - 1] + core[nk - 1] - core[nk - 1 - k];
+  euo_weight_matrix(3, q->m);
+  return 1;
+}
+
+/* inverse_lcp::eval (:289-299) for one lane: the argument arrives as double (norm / s, A.0) */
+static float inv_lcp_eval(const inv_lcp_t *q, double x)
+{
+  double t = x / q->rr_max;
+  t = sqrt(t);
+  t *= (q->nk - 1);
+  float c = (float)t;
+  /* make_safe_evaluator on a NATURAL spline: clamp gate [0, nk - 1] (map.h:231-236) */
+  float lower = 0.0f, upper = (float)(q->nk - 1);
+  float g = c;
+  if (c < lower) g = lower;
+  if (c > upper) g = upper;
+  float fl = floorf(g), delta = g - fl;
+  int sel = (int)fl;
+  float w[4];
+  weights_from_matrix(q->m, 3, delta, w);
+  const float *p = q->coef + q->left + sel - 1;
+  float sum = p[0];
+  sum *= w[0];
+  for (int i = 1; i < 4; i++) sum += w[i] * p[i];
+  return sum + 1.0f;
+}
+
+int euo_inverse_lcp(double a, double b, double c, double r_max, int sz, const float *x, long n,
+                    float *out, float *knots, int max_knots)
+{
+  inv_lcp_t q;
+  if (!inv_lcp_init(&q, a, b, c, r_max, sz)) return 0;
+  for (long i = 0; i < n; i++) out[i] = inv_lcp_eval(&q, (double)x[i]);
+  for (int i = 0; knots && i < q.nk && i < max_knots; i++) knots[i] = q.coef[q.left + i];
+  return q.nk;
+}
+
+/* ------------------------------------------------------------------------ */
 /* steppers (stepper.h) - one instance per row segment                       */
 /* ------------------------------------------------------------------------ */
 

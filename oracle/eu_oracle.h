@@ -154,6 +154,10 @@ int    euo_render(const euo_job *job, const euo_source *src, int nsrc,
 /* geometry functors, double precision, for the reference's own property
  * tests (geometry.cc:283-420) */
 void   euo_lens_factor(double a, double b, double c, const float *x, long n, float *out);
+/* inverse_lcp<float, LANES>(a, b, c, r_max, sz).eval (lens_correction.h:236-301); returns the number of
+ * knots of the model (0: too many), knots = its prefiltered core */
+int    euo_inverse_lcp(double a, double b, double c, double r_max, int sz, const float *x, long n,
+                       float *out, float *knots, int max_knots);
 void   euo_source_coordinates(const euo_source *src, const float *rays, long n, float *out3);
 void   euo_prj_to_ray_d(int projection, const double *in2, double *out3);
 void   euo_ray_to_prj_d(int projection, const double *in3, double *out2);

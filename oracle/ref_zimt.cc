@@ -280,3 +280,20 @@ extern "C" void ref_lcp_factor(double a, double b, double c, const float *x, lon
     for (std::size_t l = 0; l < L && i0 + (long)l < n; l++) out[i0 + l] = r[l];
   }
 }
+
+// inverse_lcp<float, L> (lens_correction.h:236-301) as pto_planar<T, L, true> builds it
+// (environment.h:247-252: sz = 100): the spline model of the inverse of the radial factor,
+// evaluated on 16-lane vectors; knots = the prefiltered coefficients of the model's core
+extern "C" void ref_inverse_lcp(double a, double b, double c, double r_max, int sz, const float *x,
+                                long n, float *out, float *knots, int max_knots)
+{
+  project::inverse_lcp<float, L> f(a, b, c, r_max, sz);
+  typedef zimt::simdized_type<float, L> f_v;
+  for (long i0 = 0; i0 < n; i0 += (long)L) {
+    f_v v(0.0f), r;
+    for (std::size_t l = 0; l < L && i0 + (long)l < n; l++) v[l] = x[i0 + l];
+    f.eval(v, r);
+    for (std::size_t l = 0; l < L && i0 + (long)l < n; l++) out[i0 + l] = r[l];
+  }
+  for (int i = 0; knots && i < f.nk && i < max_knots; i++) knots[i] = f.inv_model.core[i];
+}

@@ -202,6 +202,20 @@ def lens_factor(a, b, c, x):
     return out
 
 
+def inverse_lcp(a, b, c, r_max, sz, x):
+    """the oracle's inverse_lcp<float, LANES>(a, b, c, r_max, sz).eval (oracle/eu_oracle.c: inv_lcp_*);
+    returns (factors, prefiltered knots)"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    knots = np.zeros(136, np.float32)
+    f = lib().euo_inverse_lcp
+    f.restype = C.c_int
+    f.argtypes = [C.c_double] * 4 + [C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int]
+    nk = f(a, b, c, r_max, sz, x.ctypes.data, len(x), out.ctypes.data, knots.ctypes.data, len(knots))
+    assert nk > 0
+    return out, knots[:nk]
+
+
 def source_coordinates(src, rays):
     """mount_t::get_coordinate / cubemap pickup for caller-supplied rays: (n, 3) -> (n, 3) of
     {source x, source y, cube face | 0}, {0, 0, -1} for a miss"""

@@ -118,6 +118,16 @@ def main():
            "lcp_out": np.stack([refz.lcp_factor(*abc, lx) for abc in sets])}
     np.savez_compressed(os.path.join(HERE, "lcp_golden.npz"), **lcp)
     print("wrote", os.path.join(HERE, "lcp_golden.npz"))
+    # the inverse of that polynomial as pto_planar<T, L, true> builds it (sz = 100; --single jobs):
+    # factors and the model's prefiltered knots; its own file
+    ix = np.concatenate([np.linspace(0.0, 2.6, 1500).astype(np.float32), rng.random(1500, dtype=np.float32) * np.float32(2.0),
+                         np.array([0.0, 1e-8, 1.0, 5.0], np.float32)])
+    isets = np.array([[0.01, -0.03, 0.02, 1.8027756377319946, 100], [0.0, 0.0, 0.05, 1.2, 100], [-0.02, 0.01, 0.0, 2.3, 100],
+                      [0.001, 0.002, -0.004, 1.5, 32], [0.02, 0.0, 0.0, 1.8, 100]], np.float64)
+    res = [refz.inverse_lcp(*s4[:4], int(s4[4]), ix) for s4 in isets]
+    np.savez_compressed(os.path.join(HERE, "inverse_lcp_golden.npz"), x=ix, sets=isets,
+                        out=np.stack([r[0] for r in res]), knots=np.stack([np.pad(r[1], (0, 104 - len(r[1]))) for r in res]))
+    print("wrote", os.path.join(HERE, "inverse_lcp_golden.npz"))
     np.savez_compressed(os.path.join(HERE, "zimt_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "zimt_golden.npz"),
           os.path.getsize(os.path.join(HERE, "zimt_golden.npz")), "bytes")

@@ -132,3 +132,17 @@ def lcp_factor(a, b, c, x):
     f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_long, C.c_void_p]
     f(a, b, c, x.ctypes.data, len(x), out.ctypes.data)
     return out
+
+
+def inverse_lcp(a, b, c, r_max, sz, x):
+    """project::inverse_lcp<float, 16>(a, b, c, r_max, sz).eval (lens_correction.h:236-301) and the
+    prefiltered core of its spline model. NB the reference asserts when Newton's iteration does not
+    find an inverse (strong coefficients at a large r_max): keep the sets mild"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    knots = np.zeros(sz + 4, np.float32)
+    f = lib().ref_inverse_lcp
+    f.restype = None
+    f.argtypes = [C.c_double] * 4 + [C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int]
+    f(a, b, c, r_max, sz, x.ctypes.data, len(x), out.ctypes.data, knots.ctypes.data, len(knots))
+    return out, knots

@@ -126,3 +126,14 @@ def test_lens_polynomial_against_reference_fixture():
     for abc, ref in zip(G2["lcp_abc"], G2["lcp_out"]):
         got = euo.lens_factor(*abc, G2["lcp_x"])
         assert (got.view(np.uint32) == ref.view(np.uint32)).all(), abc
+
+
+def test_inverse_lens_polynomial_against_reference_fixture():
+    """oracle's inverse_lcp (the spline model of the inverse radial factor, --single jobs) against the
+    reference's own class (lens_correction.h:236-301, compiled in place by tests/golden/make_golden.py):
+    the model's prefiltered knots and its factors, bit for bit"""
+    G3 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inverse_lcp_golden.npz"))
+    for s4, ref, knots in zip(G3["sets"], G3["out"], G3["knots"]):
+        got, k = euo.inverse_lcp(*s4[:4], int(s4[4]), G3["x"])
+        assert (k.view(np.uint32) == knots[:len(k)].view(np.uint32)).all(), s4
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all(), s4

@@ -74,3 +74,16 @@ def test_lens_polynomial_sweep():
     for _ in range(40):
         a, b, c = (rng.uniform(-0.4, 0.4) for _ in range(3))
         assert (bits(euo.lens_factor(a, b, c, x)) == bits(refz.lcp_factor(a, b, c, x))).all(), (a, b, c)
+
+
+def test_inverse_lens_polynomial_sweep():
+    """inverse_lcp of the oracle against the reference's class for random mild coefficient triples"""
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.random(5000, dtype=np.float32) * np.float32(2.5), np.float32([0.0, 1e-9, 1.0, 7.0])])
+    for _ in range(25):
+        a, b, c = (rng.uniform(-0.02, 0.02) for _ in range(3))
+        r_max = rng.uniform(1.1, 2.0)
+        for sz in (32, 100):
+            o, k = euo.inverse_lcp(a, b, c, r_max, sz, x)
+            ro, rk = refz.inverse_lcp(a, b, c, r_max, sz, x)
+            assert (bits(k) == bits(rk)).all() and (bits(o) == bits(ro)).all(), (a, b, c, r_max, sz)
