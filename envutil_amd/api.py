@@ -53,7 +53,7 @@ class Target(C.Structure):
                 ("crop_w", C.c_int32), ("crop_h", C.c_int32),
                 ("out_format", C.c_int32),
                 ("band_rows", C.c_int32), ("band_count", C.c_int32), ("band_index", C.c_int32),
-                ("synopsis", C.c_int32)]
+                ("synopsis", C.c_int32), ("single", C.POINTER(Facet))]
 
 
 OUT_FLOAT, OUT_SRGBA8 = 0, 1
@@ -307,7 +307,7 @@ class arguments:
     def __init__(self, projection, width, height, hfov, yaw=0.0, pitch=0.0, roll=0.0,
                  spline_degree=1, prefilter_degree=None, twine=0, twine_width=1.0,
                  twine_sigma=0.0, twine_threshold=0.0, support_min=8, tile_size=64,
-                 crop=None, tethered=False, synopsis="panorama"):
+                 crop=None, tethered=False, synopsis="panorama", single=None):
         # store_cropped + p_crop_x0/x1/y0/y1 (envutil_basic.h:684-687) as
         # (x0, x1, y0, y1); tethered: the job writes packed sRGBA8 words
         # (args.p_screen_data, envutil_payload.cc:524-530)
@@ -318,6 +318,9 @@ class arguments:
         if synopsis not in ("panorama", "hdr_merge"):
             raise ValueError("synopsis must be panorama or hdr_merge")
         self.synopsis = synopsis
+        # args.single: the facet_spec this target recreates ((facet_base&) args = fspec, envutil_main.cc:1161-1180);
+        # projection, size, hfov and orientation of the target must be the facet's own (see for_single)
+        self.single = single
         self.projection = projection
         self.width, self.height = width, height
         self.hfov = hfov
@@ -337,6 +340,12 @@ class arguments:
             self.twine_spread = make_spread(twine, twine, twine_width, twine_sigma,
                                             twine_threshold)
 
+    @classmethod
+    def for_single(cls, fct, **kw):
+        """the target of a --single job: the facet's own geometry taken over as target geometry"""
+        return cls(fct.projection, fct.width, fct.height, fct.hfov, yaw=fct.yaw, pitch=fct.pitch, roll=fct.roll,
+                   single=fct, **kw)
+
     def target(self, nchannels, row_begin=0, row_end=None, stage=0, band=None):
         """band = (band_rows, band_count, band_index): this call renders the
         interleaved row bands of one part (eu_target.band_*); rows are local"""
@@ -354,6 +363,9 @@ class arguments:
             t.crop_x0, t.crop_y0, t.crop_w, t.crop_h = x0, y0, x1 - x0, y1 - y0
         t.out_format = OUT_SRGBA8 if self.tethered else OUT_FLOAT
         t.synopsis = SYN_HDR_MERGE if self.synopsis == "hdr_merge" else SYN_PANORAMA
+        if self.single is not None:
+            self._single_c = self.single.c_struct()          # kept alive with the arguments object
+            t.single = C.pointer(self._single_c)
         nrows = self.out_height
         if band is not None and band[1] > 1:
             t.band_rows, t.band_count, t.band_index = band

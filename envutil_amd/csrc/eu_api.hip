@@ -73,6 +73,7 @@ struct context {
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
   hipStream_t last_user = nullptr;                // caller's stream of the last render (eu_hip_sync waits on it too)
   eu_generic *mgen = nullptr; size_t mgen_cap = 0; // multi-facet jobs: the translated facets' transformations
+  float *inv_coef = nullptr;                      // --single: the inverse lens model's coefficients (eu_inv_planar)
   hipStream_t copy = nullptr;                     // D2H of a host-output frame, chunk by chunk
   hipEvent_t chunk_done[4] = { nullptr, nullptr, nullptr, nullptr };
   int *wl = nullptr; size_t wl_cap = 0;           // eu_render4.hip work list (count, done, tile ids)
@@ -340,6 +341,39 @@ int check_target(const eu_target *t)
   return EU_OK;
 }
 
+// tf22 of a --single job: the inverse planar transformation of the facet the target recreates
+// (environment.h:285-307); the inverse lens model goes to device memory (g.inv_coef)
+int build_inv_planar(const eu_target *t, eu_inv_planar *q)
+{
+  memset(q, 0, sizeof *q);
+  const eu_facet *f = t->single;
+  if (!f || !eu::has_2d_tf(*f)) return EU_OK;
+  q->shear = f->shear_g != 0.0 || f->shear_t != 0.0;
+  q->shift = f->h != 0.0 || f->v != 0.0;
+  q->lcp = f->a != 0.0 || f->b != 0.0 || f->c != 0.0;
+  q->shear_g = f->shear_g; q->shear_t = f->shear_t;
+  { // the reference radius: half the smaller edge of the facet's extent (envutil_basic.h:508-513)
+    const double dv0 = std::fabs(t->y1 - t->y0) / 2.0, dh0 = std::fabs(t->x1 - t->x0) / 2.0;
+    q->s = (dh0 < dv0) ? dh0 : dv0; }
+  q->h = (float)f->h; q->v = (float)f->v;
+  if (q->lcp) {
+    // r_max of facet_spec::process_geometry (envutil_basic.h:508-520) from the target's (= the facet's) extent
+    const double dv = std::fabs(t->y1 - t->y0) / 2.0, dh = std::fabs(t->x1 - t->x0) / 2.0;
+    const double aspect = (dh >= dv) ? dh / dv : dv / dh;
+    std::vector<float> coef;
+    if (!eu::make_inverse_lcp(f->a, f->b, f->c, std::sqrt(1 + aspect * aspect), 100, coef, q->rr_max))
+      return fail(EU_ERR_ARGUMENT, "--single: the lens polynomial has no inverse over the facet (the reference asserts here)");
+    if (g.last_user) HIPCHK(hipStreamSynchronize(g.last_user));
+    if (!g.inv_coef) HIPCHK(hipMalloc((void **)&g.inv_coef, 128 * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(g.inv_coef, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    q->nk = (int)coef.size() - 4;
+    q->coef = g.inv_coef + 2;
+    eu::weight_matrix(3, q->m);
+  }
+  return EU_OK;
+}
+
 int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *out_dev,
                  size_t row_stride_bytes, eu_render_params *p)
 {
@@ -361,12 +395,14 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
   // :2214-2224), normalised only under twining (deriv_stepper<..., generic_stepper, true>)
   eu_generic gen;
   memset(&gen, 0, sizeof gen);
-  if (eu::has_translation(s->fct) && !eu::make_generic(*t, s->fct, gen))
-    return fail(EU_ERR_UNSUPPORTED, "translated facet: no planar-to-ray functor for this target projection");
+  if ((eu::has_translation(s->fct) || eu::generic_target(*t)) && !eu::make_generic(*t, s->fct, gen))
+    return fail(EU_ERR_UNSUPPORTED, "generic stepper (translation, --single): no planar-to-ray functor for this target projection");
+  eu_inv_planar inv;
+  { int rci = build_inv_planar(t, &inv); if (rci) return rci; }
   std::vector<unsigned char> key(sizeof(eu_target) + 3 * sizeof(double) + 3 * sizeof(float) * (size_t)t->ntaps);
   {
     eu_target tk = *t;
-    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
+    tk.taps = nullptr; tk.single = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
     tk.band_rows = 0; tk.band_count = 0; tk.band_index = 0;     // the tables cover the whole frame
     unsigned char *q = key.data();
     memcpy(q, &tk, sizeof tk); q += sizeof tk;
@@ -415,6 +451,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     p->form = EU_FORM_GENERIC;
     p->norm_mode = twine ? EU_NORM_DIV : EU_NORM_NONE;
     p->gen = gen;
+    p->inv = inv;
   }
   p->twine = twine; p->ntaps = t->ntaps; p->stage = t->stage; p->nch = s->nch;
   p->nch_out = t->nchannels;
@@ -438,6 +475,7 @@ struct multi_params {
   int band_shift, band_count, band_index;
   int hdr, hdr_low, hdr_high;
   const eu_generic *gen;
+  eu_inv_planar inv;
 };
 
 // fuse() for several facets (envutil_payload.cc:2139-2180, :2240-2281): one
@@ -457,7 +495,7 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
                                  + 3 * sizeof(float) * (size_t)t->ntaps + sizeof(int));
   {
     eu_target tk = *t;
-    tk.taps = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
+    tk.taps = nullptr; tk.single = nullptr; tk.row_begin = 0; tk.row_end = 0; tk.stage = 0; tk.nchannels = 0; tk.out_format = 0;
     tk.band_rows = 0; tk.band_count = 0; tk.band_index = 0;     // the tables cover the whole frame
     unsigned char *q = key.data();
     memcpy(q, &tk, sizeof tk); q += sizeof tk;
@@ -511,9 +549,9 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   bool any_generic = false;
   for (int f = 0; f < nsrc; f++) {
     memset(&gv[f], 0, sizeof(eu_generic));
-    if (!eu::has_translation(srcs[f]->fct)) continue;
+    if (!eu::has_translation(srcs[f]->fct) && !eu::generic_target(*t)) continue;
     if (!eu::make_generic(*t, srcs[f]->fct, gv[f]))
-      return fail(EU_ERR_UNSUPPORTED, "translated facet: no planar-to-ray functor for this target projection");
+      return fail(EU_ERR_UNSUPPORTED, "generic stepper (translation, --single): no planar-to-ray functor for this target projection");
     any_generic = true;
   }
   if (any_generic) {
@@ -526,8 +564,11 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
     HIPCHK(hipMemcpyAsync(g.mgen, gv.data(), sizeof(eu_generic) * (size_t)nsrc, hipMemcpyHostToDevice, g.stream));
   }
   HIPCHK(hipStreamSynchronize(g.stream));
+  eu_inv_planar inv;
+  { int rci = build_inv_planar(t, &inv); if (rci) return rci; }
   memset(p, 0, sizeof *p);
   p->gen = any_generic ? g.mgen : nullptr;
+  p->inv = inv;
   p->width = frame_w(t); p->height = frame_h(t); p->row_begin = t->row_begin; p->row_end = t->row_end;
   if (t->band_count > 1) {
     p->band_shift = band_shift_of(t->band_rows); p->band_count = t->band_count; p->band_index = t->band_index;

@@ -72,11 +72,25 @@ inline int eu_frame_row(int yl, int shift, int count, int index)
 // generic_stepper (stepper.h:353-490) over tf_ex_facet (envutil_payload.cc:1841-1885) for a facet with
 // PTO translation parameters: planar -> ray by the TARGET's projection (roll_out_23, geometry.h:
 // 1800-1837) -> tf3d_t (geometry.h:1850-1941). Matrices are r3_t<float>, m[3 * i + c] = r[i][c].
-struct eu_generic {
-  int on, prj, has_shift;
+struct eu_tf3d {             // tf3d_t, geometry.h:1850-1941
+  int has_shift;
   float dcp;
   float shift[3];
   float trg_to_md[9], md_to_src[9], trg_to_src[9];
+};
+struct eu_generic {
+  int on, prj, ntf;          // ntf 2: tf3d1 + tf3d2 (target AND source translated, --single only)
+  eu_tf3d tf[2];
+};
+// tf22 of tf_ex_facet: pto_planar<T, L, true> of the facet a --single job recreates (environment.h:
+// 285-307) - inverse shear, inverse shift, inverse lens polynomial (inverse_lcp, lens_correction.h:
+// 236-301: a cubic b-spline model, nk knots, braced + prefiltered on the host, core at coef)
+struct eu_inv_planar {
+  int shear, shift, lcp, nk;
+  double shear_g, shear_t, s, rr_max;
+  float h, v;
+  const float *coef;         // device memory; coef[-1 .. nk + 1] are readable
+  float m[16];               // weight matrix of degree 3
 };
 
 struct eu_render_params {
@@ -100,6 +114,7 @@ struct eu_render_params {
                              // 2 32x16 tiles with direct gathers (eu_render2.hip)
   eu_src_dev src;
   eu_generic gen;            // form == EU_FORM_GENERIC
+  eu_inv_planar inv;         // ... of a --single job (all zero otherwise)
 };
 
 #endif

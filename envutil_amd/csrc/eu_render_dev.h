@@ -532,9 +532,58 @@ __device__ __forceinline__ void eu_rotate3(const float *m, float x, float y, flo
 // projection (geometry.h: ll_to_ray_t :152-211, cyl_to_ray_t :417-446, rect_to_ray_t :363-387,
 // ster_to_ray_t :481-510, fish_to_ray_t :539-566), then tf3d_t::eval (:1896-1941; its all_of / any_of
 // tests only skip work)
-__device__ __forceinline__ void eu_generic_ray(const eu_generic &g, float p0, float p1, float &rx,
-                                               float &ry, float &rz)
+__device__ __forceinline__ void eu_tf3d_eval(const eu_tf3d &g, float x, float y, float z, float &rx,
+                                             float &ry, float &rz)
 {
+  if (!g.has_shift) { eu_rotate3(g.trg_to_src, x, y, z, rx, ry, rz); return; }
+  float tx, ty, tz;
+  eu_rotate3(g.trg_to_md, x, y, z, tx, ty, tz);
+  const bool mask = tz <= 0.0f;
+  tx = tx / tz; ty = ty / tz; tz = 1.0f;
+  tx = tx * g.dcp; ty = ty * g.dcp; tz = tz * g.dcp;
+  tx = tx - g.shift[0]; ty = ty - g.shift[1]; tz = tz - g.shift[2];
+  eu_rotate3(g.md_to_src, tx, ty, tz, rx, ry, rz);
+  if (mask) { rx = 0.0f; ry = 0.0f; rz = -__builtin_huge_valf(); }
+}
+
+// inverse_lcp::eval, lens_correction.h:289-299: the argument is a double (norm / s), the spline
+// coordinate narrows to float at the evaluator; clamp gate of a NATURAL spline, cubic weights
+__device__ __forceinline__ float eu_inv_lcp(const eu_inv_planar &q, double x)
+{
+  double t = x / q.rr_max;
+  t = sqrt(t);
+  t = t * (double)(q.nk - 1);
+  const float c = (float)t, upper = (float)(q.nk - 1);
+  float g = c;
+  if (c < 0.0f) g = 0.0f;
+  if (c > upper) g = upper;
+  const float fl = floorf(g), delta = g - fl;
+  float w[4];
+  eu_weights<3>(q.m, delta, w);
+  const float *p = q.coef + (int)fl - 1;
+  float sum = p[0] * w[0];
+  sum = sum + w[1] * p[1];
+  sum = sum + w[2] * p[2];
+  sum = sum + w[3] * p[3];
+  return sum + 1.0f;
+}
+
+__device__ __forceinline__ void eu_generic_ray(const eu_generic &g, const eu_inv_planar *inv, float p0,
+                                               float p1, float &rx, float &ry, float &rz)
+{
+  if (inv) {                  // pto_planar<T, L, true>::eval, environment.h:285-307
+    if (inv->shear) {
+      p1 = (float)(((double)p1 - inv->shear_t * (double)p0) / (1 - inv->shear_t * inv->shear_g));
+      p0 = (float)((double)p0 - inv->shear_g * (double)p1);
+    }
+    if (inv->shift) { p0 = p0 - inv->h; p1 = p1 - inv->v; }
+    if (inv->lcp) {
+      float sqn = p0 * p0;
+      sqn = sqn + p1 * p1;
+      const float factor = eu_inv_lcp(*inv, (double)sqrtf(sqn) / inv->s);
+      p0 = p0 * factor; p1 = p1 * factor;
+    }
+  }
   float x, y, z;
   if (g.prj == EU_SPHERICAL) {
     const float sinlat = eu_sinf(p1), coslat = eu_cosf(p1), sinlon = eu_sinf(p0), coslon = eu_cosf(p0);
@@ -550,15 +599,8 @@ __device__ __forceinline__ void eu_generic_ray(const eu_generic &g, float p0, fl
     const float st = eu_sinf(theta);
     z = eu_cosf(theta); y = -st * eu_cosf(phi); x = st * eu_sinf(phi);
   }
-  if (!g.has_shift) { eu_rotate3(g.trg_to_src, x, y, z, rx, ry, rz); return; }
-  float tx, ty, tz;
-  eu_rotate3(g.trg_to_md, x, y, z, tx, ty, tz);
-  const bool mask = tz <= 0.0f;
-  tx = tx / tz; ty = ty / tz; tz = 1.0f;
-  tx = tx * g.dcp; ty = ty * g.dcp; tz = tz * g.dcp;
-  tx = tx - g.shift[0]; ty = ty - g.shift[1]; tz = tz - g.shift[2];
-  eu_rotate3(g.md_to_src, tx, ty, tz, rx, ry, rz);
-  if (mask) { rx = 0.0f; ry = 0.0f; rz = -__builtin_huge_valf(); }
+  eu_tf3d_eval(g.tf[0], x, y, z, rx, ry, rz);
+  if (g.ntf == 2) { const float a = rx, b = ry, c = rz; eu_tf3d_eval(g.tf[1], a, b, c, rx, ry, rz); }
 }
 
 // full stepper: tables -> ray, with the normalisation flavour of the stepper. gen / raw: the facet's
@@ -566,9 +608,10 @@ __device__ __forceinline__ void eu_generic_ray(const eu_generic &g, float p0, fl
 __device__ __forceinline__ void eu_stepper(int form, int norm_mode, const float *colA,
                                            const float *colB, const float *rowt, int x,
                                            float &rx, float &ry, float &rz,
-                                           const eu_generic *gen = nullptr, const float *raw = nullptr)
+                                           const eu_generic *gen = nullptr, const float *raw = nullptr,
+                                           const eu_inv_planar *inv = nullptr)
 {
-  if (form == EU_FORM_GENERIC) eu_generic_ray(*gen, raw[x], rowt[9], rx, ry, rz);
+  if (form == EU_FORM_GENERIC) eu_generic_ray(*gen, inv, raw[x], rowt[9], rx, ry, rz);
   else eu_ray(form, rowt, colA[x], colB[x], rx, ry, rz);
   if (norm_mode == EU_NORM_DIV) {
     float n = eu_norm3(rx, ry, rz);
@@ -617,7 +660,8 @@ __device__ __forceinline__ void eu_stepper(const eu_render_params &p, const floa
 {
   // colA is p.col (r00, r01) or p.col + 2 * width (r10): the raw planar column goes with it
   const float *raw = p.col + (colA == p.col ? 4 : 5) * (long long)p.width;
-  eu_stepper(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz, &p.gen, raw);
+  eu_stepper(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz, &p.gen, raw,
+             (p.inv.shear | p.inv.shift | p.inv.lcp) ? &p.inv : nullptr);
 }
 
 #endif

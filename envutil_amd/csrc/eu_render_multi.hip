@@ -39,6 +39,7 @@ struct eu_multi_params {
   int band_shift, band_count, band_index;   // eu_frame_row
   int hdr, hdr_low, hdr_high;               // _hdr_merge_syn: the facets that rule the shadows / the highlights
   const eu_generic *gen;                    // [nfct] or nullptr: facets stepped by generic_stepper (translation)
+  eu_inv_planar inv;                        // tf22 of a --single job
 };
 
 struct eu_pix { int x, y; };
@@ -53,7 +54,8 @@ __device__ __forceinline__ void eu_multi_ray(const eu_multi_params &p, int f, in
   if (p.gen && p.gen[f].on) {               // f is wave-uniform
     // generic_stepper<float, LANES, true>: the ray is normalised (stepper.h:431-434)
     eu_stepper(EU_FORM_GENERIC, EU_NORM_DIV, ca, ca, rowt, px.x, rx, ry, rz, &p.gen[f],
-               p.col + (variant == 1 ? 5 : 4) * (long long)p.width);
+               p.col + (variant == 1 ? 5 : 4) * (long long)p.width,
+               (p.inv.shear | p.inv.shift | p.inv.lcp) ? &p.inv : nullptr);
     return;
   }
   eu_stepper(p.form, p.norm_mode, ca, ca + p.width, rowt, px.x, rx, ry, rz);

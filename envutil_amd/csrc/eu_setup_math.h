@@ -516,6 +516,25 @@ inline void rotate_mf(const float *l, const float *r, float *o)
 }
 inline bool has_translation(const eu_facet &f) { return f.tr_x != 0 || f.tr_y != 0 || f.tr_z != 0; }
 
+inline bool has_2d_tf(const eu_facet &f)
+{
+  return f.h != 0.0 || f.v != 0.0 || f.a != 0.0 || f.b != 0.0 || f.c != 0.0 || f.shear_g != 0.0 || f.shear_t != 0.0;
+}
+// fuse(), envutil_payload.cc:2058-2069: the facet a --single job recreates has lens correction or translation
+inline bool generic_target(const eu_target &t) { return t.single && (has_2d_tf(*t.single) || has_translation(*t.single)); }
+
+inline void set_tf3d(eu_tf3d &q, const float *a, const float *b, const float *sh, float dcp)
+{
+  std::memcpy(q.trg_to_md, a, 9 * sizeof(float));
+  std::memcpy(q.md_to_src, b, 9 * sizeof(float));
+  rotate_mf(a, b, q.trg_to_src);
+  for (int c = 0; c < 3; c++) q.shift[c] = sh[c];
+  q.has_shift = q.shift[0] != 0 || q.shift[1] != 0 || q.shift[2] != 0;
+  q.dcp = dcp;
+}
+
+// generic_r3(ft, fs), envutil_payload.cc:1636-1755: ft = the job's target (with the translation of the facet
+// a --single job recreates), fs = the source facet
 inline bool make_generic(const eu_target &t, const eu_facet &f, eu_generic &g)
 {
   std::memset(&g, 0, sizeof g);
@@ -523,32 +542,125 @@ inline bool make_generic(const eu_target &t, const eu_facet &f, eu_generic &g)
     case EU_SPHERICAL: case EU_CYLINDRICAL: case EU_RECTILINEAR: case EU_STEREOGRAPHIC: case EU_FISHEYE: break;
     default: return false;
   }
-  float r_camera[9], rs_tp[9], rs_tpi[9], r_facet[9];
+  double ft6[6] = { 0, 0, 0, 0, 0, 0 };
+  if (t.single) { ft6[0] = t.single->tr_x; ft6[1] = t.single->tr_y; ft6[2] = t.single->tr_z;
+                  ft6[3] = t.single->tp_y; ft6[4] = t.single->tp_p; ft6[5] = t.single->tp_r; }
+  float r_camera[9], rt_tp[9], rt_tpi[9], rs_tp[9], rs_tpi[9], r_facet[9];
   r3f(t.roll, t.pitch, t.yaw, false, r_camera);
+  r3f(ft6[5], ft6[4], ft6[3], true, rt_tp);
+  r3f(ft6[5], ft6[4], ft6[3], false, rt_tpi);
   r3f(f.tp_r, f.tp_p, f.tp_y, true, rs_tp);
   r3f(f.tp_r, f.tp_p, f.tp_y, false, rs_tpi);
   r3f(f.roll, f.pitch, f.yaw, true, r_facet);
-  float sh[3] = { (float)f.tr_x, (float)f.tr_y, (float)f.tr_z };
-  if (f.tp_y != 0 || f.tp_p != 0 || f.tp_r != 0) {
-    // rotate(xel_t<double,3>(shift_s), rs_tp): double vector, float matrix, narrowed on assignment
+  const bool have_ttp = ft6[0] != 0 || ft6[1] != 0 || ft6[2] != 0, have_stp = has_translation(f);
+  // rotate(xel_t<double,3>(shift), r_tp): double vector, float matrix, narrowed on assignment
+  auto to_plane = [](float *sh, const float *m) {
     const double v[3] = { sh[0], sh[1], sh[2] };
     for (int c = 0; c < 3; c++)
-      sh[c] = (float)((v[0] * (double)rs_tp[c] + v[1] * (double)rs_tp[3 + c]) + v[2] * (double)rs_tp[6 + c]);
-  }
-  if (has_translation(f)) {
-    rotate_mf(r_camera, rs_tp, g.trg_to_md);
-    rotate_mf(rs_tpi, r_facet, g.md_to_src);
-    rotate_mf(g.trg_to_md, g.md_to_src, g.trg_to_src);
-    for (int c = 0; c < 3; c++) g.shift[c] = sh[c];
+      sh[c] = (float)((v[0] * (double)m[c] + v[1] * (double)m[3 + c]) + v[2] * (double)m[6 + c]);
+  };
+  float shift_t[3] = { (float)ft6[0], (float)ft6[1], (float)ft6[2] };
+  if (ft6[3] != 0 || ft6[4] != 0 || ft6[5] != 0) to_plane(shift_t, rt_tp);
+  const float dcp = (float)(1.0 - (double)shift_t[2]);
+  for (int c = 0; c < 3; c++) shift_t[c] = -shift_t[c];
+  float shift_s[3] = { (float)f.tr_x, (float)f.tr_y, (float)f.tr_z };
+  if (f.tp_y != 0 || f.tp_p != 0 || f.tp_r != 0) to_plane(shift_s, rs_tp);
+  const float zero3[3] = { 0.0f, 0.0f, 0.0f };
+  float m1[9], m2[9];
+  g.ntf = 1;
+  if (have_ttp && have_stp) {
+    rotate_mf(r_camera, rt_tp, m1);
+    set_tf3d(g.tf[0], m1, rt_tpi, shift_t, dcp);
+    rotate_mf(rs_tpi, r_facet, m2);
+    set_tf3d(g.tf[1], rs_tp, m2, shift_s, 1.0f);
+    g.ntf = 2;
+  } else if (have_ttp) {
+    rotate_mf(r_camera, rt_tp, m1);
+    rotate_mf(rt_tpi, r_facet, m2);
+    set_tf3d(g.tf[0], m1, m2, shift_t, dcp);
+  } else if (have_stp) {
+    rotate_mf(r_camera, rs_tp, m1);
+    rotate_mf(rs_tpi, r_facet, m2);
+    set_tf3d(g.tf[0], m1, m2, shift_s, 1.0f);
   } else {
-    std::memcpy(g.trg_to_md, r_camera, sizeof r_camera);
-    std::memcpy(g.md_to_src, r_facet, sizeof r_facet);
-    rotate_mf(r_camera, r_facet, g.trg_to_src);
+    set_tf3d(g.tf[0], r_camera, r_facet, zero3, 1.0f);
   }
-  g.dcp = 1.0f;
-  g.has_shift = g.shift[0] != 0 || g.shift[1] != 0 || g.shift[2] != 0;
   g.prj = t.projection;
   g.on = 1;
+  return true;
+}
+
+// inverse_lcp (lens_correction.h:236-301) as pto_planar<T, L, true> builds it for the facet of a --single
+// job (environment.h:247-252: sz = 100; r_max from the facet's extent, envutil_basic.h:508-520): Newton
+// iteration per knot in double (eu_polynomial::inverse, :112-139), the knots prefiltered as a cubic NATURAL
+// b-spline (recursive.h:631-733 for one pole) and braced. coef: nk + 4 floats, the core starts at coef + 2.
+// false: the polynomial has no inverse there (the reference asserts).
+inline bool make_inverse_lcp(double a, double b, double c, double r_max_in, int sz, std::vector<float> &coef,
+                             double &rr_max)
+{
+  const double cf[5] = { a, b, c, 1.0 - (a + b + c), 0.0 };
+  double dcf[5];
+  { int power = 4; for (int i = 0; i <= 4; i++) { dcf[i] = cf[i] * power; --power; } }
+  auto fn = [&](double x) { double sum = 0.0, power = 1.0; for (int i = 0; i <= 4; i++) { sum += cf[4 - i] * power; power *= x; } return sum; };
+  auto dfn = [&](double x) { double sum = 0.0, power = 1.0; for (int i = 0; i < 4; i++) { sum += dcf[4 - i - 1] * power; power *= x; } return sum; };
+  const int nk = sz + 4;
+  const double r_max = r_max_in * ((sz + 3.0) / sz);
+  rr_max = fn(r_max);
+  coef.assign((size_t)nk + 4, 0.0f);
+  float *core = coef.data() + 2;
+  for (int i = 0; i < nk; i++) {
+    double notch = (double)i / (nk - 1);
+    notch *= notch;
+    notch *= rr_max;
+    double out = i * r_max / sz;
+    const double tolerance = 100 * 2.220446049250313e-16;
+    double current = out, result, difference = 0.0, last_difference = 1.7976931348623157e308;
+    for (int count = 0; count < 16; count++) {
+      result = fn(current);
+      difference = notch - result;
+      if (last_difference == difference) break;
+      if (std::fabs(difference) <= tolerance) break;
+      last_difference = difference;
+      current = current + difference / dfn(current);
+    }
+    if (!(std::fabs(difference) < tolerance)) return false;
+    out = current;
+    core[i] = (float)(notch == 0.0 ? 1.0 / dfn(0.0) : (out / notch) - 1);
+  }
+  // prefilter: degree 3, one pole, NATURAL, tolerance = float epsilon (bspline.h:1017-1041)
+  long double lp[8];
+  poles(3, lp);
+  const float p = (float)lp[0];
+  const float g = (float)((1.0L - lp[0]) * (1.0L - 1.0L / lp[0]));
+  const int hz = (int)std::ceil(std::log((long double)1.1920928955078125e-07L) / std::log(std::fabs(lp[0])));
+  const int M = nk;
+  float X;
+  {
+    // icc NATURAL (recursive.h:321-360)
+    if (hz < M) {
+      const float c02 = core[0] + core[0];
+      float zn = p, Sum = core[0];
+      for (int n = 1; n < hz; n++) { Sum = Sum + zn * (c02 - core[n]); zn = zn * p; }
+      X = Sum;
+    } else {
+      float zn = p, iz = 1.0f / p, z2n = (float)std::pow(lp[0], (long double)(M - 1));
+      float Sum = ((1.0f + p) / (1.0f - p)) * (core[0] - z2n * core[M - 1]);
+      z2n = z2n * (z2n * iz);
+      for (int n = 1; n <= M - 2; n++) { Sum = Sum - (zn - z2n) * core[n]; zn = zn * p; z2n = z2n * iz; }
+      X = Sum / (1.0f - zn * zn);
+    }
+  }
+  X = g * X;
+  core[0] = X;
+  for (int n = 1; n < M; n++) { X = g * core[n] + p * X; core[n] = X; }
+  X = -(p / ((1.0f - p) * (1.0f - p))) * (core[M - 1] - p * core[M - 2]);   // iacc NATURAL
+  core[M - 1] = X;
+  for (int n = M - 2; n >= 0; n--) { X = p * (X - core[n]); core[n] = X; }
+  // NATURAL brace (brace.h:134+): point mirror on the first / last core value
+  for (int k = 1; k <= 2; k++) {
+    core[-k] = core[0] + core[0] - core[k];
+    core[nk - 1 + k] = core[nk - 1] + core[nk - 1] - core[nk - 1 - k];
+  }
   return true;
 }
 

@@ -188,11 +188,15 @@ struct hip_dispatch : public dispatch_base
     // reference's CPU dispatch keeps them; an unknown synopsis is the reference's assert(false)
     // (envutil_payload.cc:2316-2318)
     if (args.synopsis != "panorama" && args.synopsis != "hdr_merge") return EU_ERR_ARGUMENT;
-    if (args.single >= 0 || !args.split.empty()) return EU_ERR_UNSUPPORTED;
+    // --split is the caller's loop over --single jobs (core(), envutil_main.cc:1676-1722)
+    if (args.single >= int(args.facet_spec_v.size()) || args.solo >= int(args.facet_spec_v.size())) return EU_ERR_ARGUMENT;
     for (const auto &fct : args.facet_spec_v)
       if (fct.has_pto_mask || fct.has_lens_crop || fct.masked != -1) return EU_ERR_UNSUPPORTED;
     std::vector<eu_source *> srcs;
-    for (const auto &fct : args.facet_spec_v) {
+    for (size_t fi = 0; fi < args.facet_spec_v.size(); fi++) {
+      // --solo: only that facet takes part (fuse(), envutil_payload.cc:2085-2127)
+      if (args.solo >= 0 && int(fi) != args.solo) continue;
+      const auto &fct = args.facet_spec_v[fi];
       auto it = resident.find(fct.asset_key);
       if (it == resident.end()) {
         eu_facet e = to_eu(fct);
@@ -224,6 +228,13 @@ struct hip_dispatch : public dispatch_base
     }
     t.row_begin = 0; t.row_end = h; t.stage = 0;
     t.synopsis = args.synopsis == "hdr_merge" ? EU_SYN_HDR_MERGE : EU_SYN_PANORAMA;
+    // --single: args carries the facet's geometry ((facet_base&) args = fspec); its lens and translation
+    // parameters reach the library through eu_target.single
+    eu_facet single_fct {};
+    if (args.single >= 0) {
+      single_fct = to_eu(args.facet_spec_v[size_t(args.single)]);
+      t.single = &single_fct;
+    }
     if (args.tethered) {
       t.out_format = EU_OUT_SRGBA8;
       return eu_hip_render(&t, srcs.data(), int(srcs.size()), (float *)args.p_screen_data,

@@ -130,6 +130,13 @@ typedef struct eu_target {
    * voronoi_syn_plus (2/4 channels); EU_SYN_HDR_MERGE: _hdr_merge_syn (envutil_payload.cc:
    * 1325-1626), the quality-weighted sum of ALL facets. Ignored for single-facet jobs.        */
   int32_t synopsis;
+  /* args.single (envutil_main.cc:1161-1180; envutil_payload.cc:2058-2069): the target RECREATES this facet.
+   * Projection, size, extent and orientation above are then the facet's own ((facet_base&) args = fspec);
+   * this pointer hands over what a target otherwise does not have - lens polynomial, shift, shear and
+   * translation - and when any of them is set every facet of the job is stepped by generic_stepper over
+   * tf_ex_facet with the inverse planar transformation (pto_planar<T, L, true>, inverse_lcp) and the
+   * inverse translation. Host pointer, read during the call; NULL: an ordinary target.            */
+  const eu_facet *single;
 } eu_target;
 
 /* How the library would lay the job's rows out (eu_api.hip: launch-level choice between

@@ -1141,8 +1141,13 @@ typedef struct {
   int x_off, y_off;              /* bill.get_offset (wielding.h:215-224)   */
   /* generic_stepper (stepper.h:353-490) over tf_ex_facet (envutil_payload.cc:1841-1885): used for
    * a facet with translation parameters. tf33 = generic_r3, a tf3d_t (geometry.h:1850-1941) */
-  int generic, has_shift;
-  float trg_to_md[9], md_to_src[9], trg_to_src[9], shift[3], dcp;   /* r3_t<float>: m[3 * i + c] = r[i][c] */
+  int generic, ntf;
+  struct tf3d { int has_shift; float trg_to_md[9], md_to_src[9], trg_to_src[9], shift[3], dcp; } tf[2];   /* r3_t<float>: m[3 * i + c] = r[i][c] */
+  /* tf22 = pto_planar<T, L, true> of the target (environment.h:285-307), --single only */
+  int inv_shear, inv_shift, inv_lcp;
+  double shear_g, shear_t, inv_s;
+  float inv_h, inv_v;
+  const inv_lcp_t *inv_model;
 } stepper_t;
 
 /* rotate(xel_t<U,3>, r3_t<T>), geometry.h:80-87: (lhs[0] * rhs[0]) + (lhs[1] * rhs[1]) + (lhs[2] * rhs[2]) */
@@ -1197,29 +1202,34 @@ static void generic_r3_init(stepper_t *s, const double *ft_rpy, const double *ft
     for (int c = 0; c < 3; c++) o[c] = (v[0] * (double)rs_tp[c] + v[1] * (double)rs_tp[3 + c]) + v[2] * (double)rs_tp[6 + c];
     for (int c = 0; c < 3; c++) shift_s[c] = (float)o[c];
   }
-  const float *sh = NULL;
-  s->dcp = 1.0f;
-  if (have_ttp && have_stp) {
-    s->generic = 2;              /* tf3d1 + tf3d2: two chained tf3d_t - not restated (only --single reaches it) */
-    return;
-  } else if (have_ttp) {
-    rotate_m_f(r_camera, rt_tp, s->trg_to_md);
-    rotate_m_f(rt_tpi, r_facet, s->md_to_src);
-    sh = shift_t; s->dcp = dcp;
-  } else if (have_stp) {
-    rotate_m_f(r_camera, rs_tp, s->trg_to_md);
-    rotate_m_f(rs_tpi, r_facet, s->md_to_src);
-    sh = shift_s;
-  } else {
-    float id[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
-    memcpy(s->trg_to_md, r_camera, sizeof id);
-    memcpy(s->md_to_src, r_facet, sizeof id);
+  /* tf3d_t ctor (geometry.h:1866-1879) */
+#define TF3D_SET(T, A, B, SH, DCP) do { \
+    memcpy((T)->trg_to_md, (A), 9 * sizeof(float)); memcpy((T)->md_to_src, (B), 9 * sizeof(float)); \
+    rotate_m_f((A), (B), (T)->trg_to_src); \
+    for (int c_ = 0; c_ < 3; c_++) (T)->shift[c_] = (SH)[c_]; \
+    (T)->has_shift = (T)->shift[0] != 0 || (T)->shift[1] != 0 || (T)->shift[2] != 0; \
+    (T)->dcp = (DCP); } while (0)
+  float m1[9], m2[9];
+  const float zero3[3] = { 0.0f, 0.0f, 0.0f };
+  s->ntf = 1;
+  if (have_ttp && have_stp) {          /* case 1: tf3d1 + tf3d2 */
+    rotate_m_f(r_camera, rt_tp, m1);
+    TF3D_SET(&s->tf[0], m1, rt_tpi, shift_t, dcp);
+    rotate_m_f(rs_tpi, r_facet, m2);
+    TF3D_SET(&s->tf[1], rs_tp, m2, shift_s, 1.0f);
+    s->ntf = 2;
+  } else if (have_ttp) {               /* case 2 */
+    rotate_m_f(r_camera, rt_tp, m1);
+    rotate_m_f(rt_tpi, r_facet, m2);
+    TF3D_SET(&s->tf[0], m1, m2, shift_t, dcp);
+  } else if (have_stp) {               /* case 3 */
+    rotate_m_f(r_camera, rs_tp, m1);
+    rotate_m_f(rs_tpi, r_facet, m2);
+    TF3D_SET(&s->tf[0], m1, m2, shift_s, 1.0f);
+  } else {                             /* case 4: rotate_t(rotate(r_camera, r_facet)) */
+    TF3D_SET(&s->tf[0], r_camera, r_facet, zero3, 1.0f);
   }
-  rotate_m_f(s->trg_to_md, s->md_to_src, s->trg_to_src);
-  if (!have_ttp && !have_stp) rotate_m_f(r_camera, r_facet, s->trg_to_src);   /* rotate_t(r_complete) */
-  s->shift[0] = s->shift[1] = s->shift[2] = 0.0f;
-  if (sh) { s->shift[0] = sh[0]; s->shift[1] = sh[1]; s->shift[2] = sh[2]; }
-  s->has_shift = s->shift[0] != 0 || s->shift[1] != 0 || s->shift[2] != 0;
+#undef TF3D_SET
   s->generic = 1;
 }
 
@@ -1256,7 +1266,7 @@ static int planar_to_ray_f(int projection, const float *in, float *out)
 }
 
 /* tf3d_t::eval, geometry.h:1896-1941; the all_of / any_of tests only skip work */
-static void tf3d_eval(const stepper_t *s, const float *in, float *out)
+static void tf3d_eval(const struct tf3d *s, const float *in, float *out)
 {
   if (!s->has_shift) { rotate_f(in, s->trg_to_src, out); return; }
   float t[3];
@@ -1300,9 +1310,23 @@ static void stepper_init(stepper_t *s, int projection, int normalize,
 
 /* fuse() (envutil_payload.cc:2095-2110, :2145-2158): a facet with translation parameters gets
  * generic_stepper(tf_ex_facet(args, fct)); returns 0 when this build does not restate the case */
-static int stepper_make_generic(stepper_t *s, const euo_job *job, const euo_source *src)
+static int stepper_make_generic(stepper_t *s, const euo_job *job, const euo_source *src, const inv_lcp_t *inv_model)
 {
   double ft_rpy[3] = { job->roll, job->pitch, job->yaw }, ft6[6] = { 0, 0, 0, 0, 0, 0 };
+  s->inv_shear = s->inv_shift = s->inv_lcp = 0;
+  s->inv_model = inv_model;
+  if (job->single) {
+    const euo_source *t = job->single;
+    ft6[0] = t->tr_x; ft6[1] = t->tr_y; ft6[2] = t->tr_z; ft6[3] = t->tp_y; ft6[4] = t->tp_p; ft6[5] = t->tp_r;
+    s->inv_shear = t->shear_g != 0.0 || t->shear_t != 0.0;
+    s->inv_shift = t->h != 0.0 || t->v != 0.0;
+    s->inv_lcp = t->a != 0.0 || t->b != 0.0 || t->c != 0.0;
+    s->shear_g = t->shear_g; s->shear_t = t->shear_t;
+    s->inv_h = (float)t->h; s->inv_v = (float)t->v;
+    { /* facet_spec::process_geometry: the reference radius is half the smaller edge (envutil_basic.h:508-513) */
+      double dv = fabs(job->y1 - job->y0) / 2.0, dh = fabs(job->x1 - job->x0) / 2.0;
+      s->inv_s = (dh < dv) ? dh : dv; }
+  }
   double fs_rpy[3] = { src->roll, src->pitch, src->yaw };
   double fs6[6] = { src->tr_x, src->tr_y, src->tr_z, src->tp_y, src->tp_p, src->tp_r };
   float probe[2] = { 0.0f, 0.0f }, r[3];
@@ -1311,6 +1335,24 @@ static int stepper_make_generic(stepper_t *s, const euo_job *job, const euo_sour
   return s->generic == 1;
 }
 static int has_translation(const euo_source *src) { return src->tr_x != 0 || src->tr_y != 0 || src->tr_z != 0; }
+/* fuse(), envutil_payload.cc:2058-2069: the single facet has lens correction or translation */
+static int generic_target(const euo_job *job)
+{
+  const euo_source *t = job->single;
+  if (!t) return 0;
+  int has_2d_tf = t->h != 0.0 || t->v != 0.0 || t->a != 0.0 || t->b != 0.0 || t->c != 0.0 || t->shear_g != 0.0 || t->shear_t != 0.0;
+  return has_2d_tf || has_translation(t);
+}
+/* the inverse lens model of the single facet: r_max from the facet's extent (facet_spec::process_geometry,
+ * envutil_basic.h:508-520), sz = 100 (environment.h:251) */
+static int single_inv_model(const euo_job *job, inv_lcp_t *q)
+{
+  const euo_source *t = job->single;
+  if (!t || !(t->a != 0.0 || t->b != 0.0 || t->c != 0.0)) return 1;
+  double dv = fabs(job->y1 - job->y0) / 2.0, dh = fabs(job->x1 - job->x0) / 2.0;
+  double aspect = (dh >= dv) ? dh / dv : dv / dh;
+  return inv_lcp_init(q, t->a, t->b, t->c, sqrt(1 + aspect * aspect), 100);
+}
 
 /* planar coordinate of pixel (x, y): stepper.h:324-350. The x value is the
  * segment-start value of the pixel's lane plus k additions of delta. */
@@ -1347,8 +1389,21 @@ static void stepper_ray(const stepper_t *s, int x, int y, float *trg)
   planar_at(s, x, y, pl);
   if (s->generic) {             /* generic_stepper::init / increase, stepper.h:422-473 */
     float r[3];
+    /* tf_ex_facet::eval (envutil_payload.cc:1869-1884): tf22 (if has_2d_tf), tf23, tf33 */
+    if (s->inv_shear) {           /* pto_planar<T, L, true>, environment.h:290-295: doubles, narrowed on assignment */
+      pl[1] = (float)(((double)pl[1] - s->shear_t * (double)pl[0]) / (1 - s->shear_t * s->shear_g));
+      pl[0] = (float)((double)pl[0] - s->shear_g * (double)pl[1]);
+    }
+    if (s->inv_shift) { pl[0] -= s->inv_h; pl[1] -= s->inv_v; }
+    if (s->inv_lcp) {
+      float sqn = pl[0] * pl[0];
+      sqn += pl[1] * pl[1];
+      float factor = inv_lcp_eval(s->inv_model, (double)sqrtf(sqn) / s->inv_s);
+      pl[0] *= factor; pl[1] *= factor;
+    }
     planar_to_ray_f(s->projection, pl, r);
-    tf3d_eval(s, r, trg);
+    tf3d_eval(&s->tf[0], r, trg);
+    if (s->ntf == 2) { float t[3] = { trg[0], trg[1], trg[2] }; tf3d_eval(&s->tf[1], t, trg); }
     if (s->normalize) normalize3(trg);
     return;
   }
@@ -1947,6 +2002,8 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
   syn_t *sy = (syn_t *)calloc(1, sizeof(syn_t));
   stepper_t *st = (stepper_t *)calloc(3 * (size_t)nsrc, sizeof(stepper_t));
   sy->nfct = nsrc; sy->nch = nch; sy->plus = (nch == 2 || nch == 4);
+  static _Thread_local inv_lcp_t inv_model;
+  if (!single_inv_model(job, &inv_model)) { free(sy); free(st); return -5; }
   double r_cam[9];
   euo_make_r3(job->roll, job->pitch, job->yaw, 0, r_cam);
   for (int f = 0; f < nsrc; f++) {
@@ -1961,9 +2018,9 @@ static int euo_render_multi(const euo_job *job, const euo_source *srcs, int nsrc
     stepper_init(&st[3 * f + 2], job->projection, 1, basis, job->width, job->height, job->x0, job->x1, job->y0, job->y1, 0.0f, 0.25f);
     if (job->crop_w > 0)
       for (int v = 0; v < 3; v++) { st[3 * f + v].x_off = job->crop_x0; st[3 * f + v].y_off = job->crop_y0; }
-    if (has_translation(&srcs[f]))
+    if (has_translation(&srcs[f]) || generic_target(job))
       for (int v = 0; v < 3; v++)
-        if (!stepper_make_generic(&st[3 * f + v], job, &srcs[f])) { free(sy); free(st); return -4; }
+        if (!stepper_make_generic(&st[3 * f + v], job, &srcs[f], &inv_model)) { free(sy); free(st); return -4; }
     mount_init(&sy->mnt[f], &srcs[f]);
     sy->recip_step[f] = (float)(1.0 / srcs[f].step);
     sy->optimum[f] = 0.5f * (float)srcs[f].brighten;
@@ -2075,10 +2132,12 @@ int euo_render(const euo_job *job, const euo_source *srcs, int nsrc,
     st00.x_off = st10.x_off = st01.x_off = job->crop_x0;
     st00.y_off = st10.y_off = st01.y_off = job->crop_y0;
   }
-  if (has_translation(src)) {
+  inv_lcp_t inv_model;
+  if (!single_inv_model(job, &inv_model)) return -5;
+  if (has_translation(src) || generic_target(job)) {
     /* generic_stepper<float, LANES, false> / deriv_stepper<..., generic_stepper, true> (payload.cc:2095-2110, :2214-2224) */
-    if (!stepper_make_generic(&st00, job, src) || !stepper_make_generic(&st10, job, src) ||
-        !stepper_make_generic(&st01, job, src)) return -4;
+    if (!stepper_make_generic(&st00, job, src, &inv_model) || !stepper_make_generic(&st10, job, src, &inv_model) ||
+        !stepper_make_generic(&st01, job, src, &inv_model)) return -4;
   }
   float lut[257];
   euo_screen_lut(lut);

@@ -95,6 +95,11 @@ typedef struct {
   /* args.synopsis for several facets: 0 "panorama" (voronoi_syn / voronoi_syn_plus by channel
    * count), 1 "hdr_merge" (_hdr_merge_syn, envutil_payload.cc:1325-1626) */
   int synopsis;
+  /* args.single (envutil_main.cc:1161-1180, envutil_payload.cc:2058-2069): the target recreates this
+   * facet - the job's projection, size, extent and orientation are the facet's, and when it has lens
+   * parameters (a, b, c, h, v, shear) or translation every facet is stepped by generic_stepper over
+   * tf_ex_facet with the INVERSE planar transformation and the inverse translation. NULL: none. */
+  const euo_source *single;
 } euo_job;
 
 /* to_screen_t's LUT (256 knots of 255 * sRGB(i / 255), float) and one pixel */

@@ -50,7 +50,7 @@ class Job(C.Structure):
                 ("row_begin", C.c_int), ("row_end", C.c_int),
                 ("stage", C.c_int), ("nthreads", C.c_int),
                 ("crop_x0", C.c_int), ("crop_y0", C.c_int), ("crop_w", C.c_int), ("crop_h", C.c_int),
-                ("screen", C.c_int), ("synopsis", C.c_int)]
+                ("screen", C.c_int), ("synopsis", C.c_int), ("single", C.POINTER(Source))]
 
 
 class Metrics(C.Structure):

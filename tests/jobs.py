@@ -168,6 +168,9 @@ def oracle_render(args, osrc, stage=0, row_begin=0, row_end=None, nthreads=8, nc
     j.stage = stage
     j.nthreads = nthreads
     j.synopsis = 1 if getattr(args, "synopsis", "panorama") == "hdr_merge" else 0
+    if getattr(args, "single", None) is not None:
+        # --single: the target recreates this facet (an OracleSource built with the same parameters)
+        j.single = C.pointer(args.single_oracle.s)
     w = args.width
     if getattr(args, "store_cropped", False):
         x0, x1, y0, y1 = args.p_crop

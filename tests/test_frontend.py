@@ -288,3 +288,37 @@ def test_pto_mosaic_with_translation_to_pixels(demo, tmp_path):
                            translation=dict(x=0.2, y=-0.05, z=-0.1, tp_y=5.0, tp_p=-3.0))
     a = ea.arguments(ea.RECTILINEAR, 260, 180, 90.0, spline_degree=1)
     assert fnv1a(jobs.oracle_render(a, [o0, o1])) == got
+
+
+@pytest.mark.gpu
+def test_single_command_line_to_pixels(demo, tmp_path):
+    """--single 1 on a PTO whose second image has a lens polynomial, a shift and a translation: the front end
+    takes the facet's geometry over as target geometry, payload() hands its lens and translation parameters to
+    the library (eu_target.single), every facet goes through generic_stepper == the oracle"""
+    import euo
+    import jobs
+    from test_cpp_dispatch import fnv1a
+    (tmp_path / "un.pto").write_text(
+        'p f2 w400 h200 v360 n"TIFF"\n'
+        'i w200 h150 f0 v60 y-10 p0 r0 n"a.tif"\n'
+        'i w180 h140 f0 v55 y8 p3 r2 a0.01 b-0.02 c0.015 d4 e-3 TrX0.1 TrY-0.04 TrZ0.05 Tpy2 Tpp-1 n"b.tif"\n')
+    j, tail = demo(["--pto", "un.pto", "--single", "1", "--output", "o.tif", "--degree", "1", "--twine", "0"],
+                   {"a.tif": (200, 150, 3), "b.tif": (180, 140, 3)}, cwd=str(tmp_path), render=True)
+    assert j["ok"] and "rc 0" in tail, tail
+    assert (j["projection"], j["width"], j["height"]) == (ea.RECTILINEAR, 180, 140)
+    got = tail.split("fnv1a")[1].strip()
+    fb = j["facets"][1]
+
+    def pixels(k, w, h, n):
+        y, x, c = np.indices((h, w, n))
+        return (np.float32(0.5) + np.float32(0.25) * ((x * 7 + y * 13 + c * 29 + k * 5) % 97).astype(np.float32)
+                / np.float32(97.0)).astype(np.float32)
+    lens = dict(a=fb["a"], b=fb["b"], c=fb["c"], h=fb["h"], v=fb["v"])
+    tr = dict(x=0.1, y=-0.04, z=-0.05, tp_y=2.0, tp_p=-1.0)
+    o0 = jobs.OracleSource(euo.RECTILINEAR, 200, 150, 60.0, pixels(0, 200, 150, 3), 1, yaw=-10.0)
+    o1 = jobs.OracleSource(euo.RECTILINEAR, 180, 140, 55.0, pixels(1, 180, 140, 3), 1, yaw=8.0, pitch=3.0, roll=2.0, lens=lens,
+                           translation=tr)
+    a = ea.arguments.for_single(ea.facet_spec(ea.RECTILINEAR, 180, 140, 55.0, yaw=8.0, pitch=3.0, roll=2.0, lens=lens,
+                                              translation=tr), spline_degree=1)
+    a.single_oracle = o1
+    assert fnv1a(jobs.oracle_render(a, [o0, o1])) == got

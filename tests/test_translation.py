@@ -115,3 +115,65 @@ def test_translated_facet_on_a_cubemap_target_is_refused():
     a = ea.arguments(ea.CUBEMAP, 32, 192, 90.0, spline_degree=1)
     with pytest.raises(Exception):
         ea.render(a, g, 3)
+
+
+# ---- --single: the target recreates a facet (inverse lens correction, inverse translation) -------------
+
+def single_job(prj, w, h, hfov, lens, translation, gpu, nfacets=3, nch=3, degree=1, **kw):
+    """the facet to recreate (its pixels are not used: only its geometry) and a few source facets around it"""
+    fspec = ea.facet_spec(prj, w, h, hfov, nchannels=nch, yaw=4.0, pitch=-2.0, roll=1.0, lens=lens, translation=translation)
+    single_o = jobs.OracleSource(prj, w, h, hfov, jobs.synth_image(w, h, nch, seed=1), degree, yaw=4.0, pitch=-2.0, roll=1.0,
+                                 lens=lens, translation=translation)
+    a = ea.arguments.for_single(fspec, spline_degree=degree, **kw)
+    a.single_oracle = single_o
+    os_, gs = [], []
+    for k in range(nfacets):
+        tr = None if k != 1 else dict(x=0.1, y=0.05, z=-0.04, tp_y=3.0, tp_p=2.0)
+        o, g = facet(euo.RECTILINEAR, 110, 90, 75.0, nch, degree, tr, gpu, seed=30 + k, yaw=4.0 + 20.0 * (k - 1), pitch=-2.0 + 3.0 * k,
+                     brighten=1.0 + 0.1 * k)
+        os_.append(o)
+        gs.append(g)
+    return a, os_, gs
+
+
+def test_single_without_lens_or_translation_is_an_ordinary_job():
+    a, os_, _ = single_job(euo.RECTILINEAR, 120, 90, 70.0, None, None, False, nfacets=1)
+    b = ea.arguments(ea.RECTILINEAR, 120, 90, 70.0, yaw=4.0, pitch=-2.0, roll=1.0, spline_degree=1)
+    assert (jobs.bits(jobs.oracle_render(a, os_)) == jobs.bits(jobs.oracle_render(b, os_))).all()
+
+
+def test_single_undoes_the_lens_correction_of_the_facet_it_recreates():
+    """a facet seen through its own lens parameters, recreated with --single from itself, is the facet:
+    the inverse planar transformation of the target and the forward one of the source cancel"""
+    lens = dict(a=0.01, b=-0.03, c=0.02, h=0.02, v=-0.01)
+    img = jobs.synth_image(160, 120, 3, seed=7)
+    src = jobs.OracleSource(euo.RECTILINEAR, 160, 120, 70.0, img, 1, yaw=4.0, pitch=-2.0, roll=1.0, lens=lens)
+    fspec = ea.facet_spec(euo.RECTILINEAR, 160, 120, 70.0, yaw=4.0, pitch=-2.0, roll=1.0, lens=lens)
+    a = ea.arguments.for_single(fspec, spline_degree=1)
+    a.single_oracle = src
+    out = jobs.oracle_render(a, src)
+    inner = out[10:-10, 10:-10]
+    assert (inner[:, :, 0] != 0).all()
+    np.testing.assert_allclose(inner, img[10:-10, 10:-10], rtol=0, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lens,translation", [
+    (dict(a=0.01, b=-0.03, c=0.02), None),
+    (dict(h=0.03, v=-0.02, g=0.01, t=-0.02), None),
+    (dict(a=0.02, b=0.0, c=-0.01, h=0.01, v=0.02, g=0.005, t=0.004), dict(x=0.08, y=-0.03, z=0.05, tp_y=2.0, tp_p=-1.0)),
+    (None, dict(x=-0.1, y=0.02, z=0.0)),
+])
+@pytest.mark.parametrize("prj,w,h,hfov", [(euo.RECTILINEAR, 130, 100, 70.0), (euo.FISHEYE, 110, 110, 140.0),
+                                          (euo.SPHERICAL, 160, 80, 120.0)])
+def test_single_jobs_bit_exact(prj, w, h, hfov, lens, translation):
+    for nf, twine, syn in [(1, 0, "panorama"), (3, 0, "panorama"), (3, 2, "panorama"), (3, 0, "hdr_merge")]:
+        a, os_, gs = single_job(prj, w, h, hfov, lens, translation, True, nfacets=nf, twine=twine, synopsis=syn)
+        assert_bits(ea.render(a, gs, 3), jobs.oracle_render(a, os_), f"--single {prj} lens {lens} tr {translation} nf {nf} twine {twine} {syn}")
+
+
+@pytest.mark.gpu
+def test_single_with_a_lens_polynomial_that_has_no_inverse_is_an_error():
+    a, os_, gs = single_job(euo.RECTILINEAR, 100, 80, 70.0, dict(a=-0.3, b=0.0, c=0.0), None, True, nfacets=1)
+    with pytest.raises(Exception):
+        ea.render(a, gs, 3)
