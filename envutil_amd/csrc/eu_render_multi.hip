@@ -23,7 +23,7 @@
 // loop (readlane makes the index uniform, the lanes that want it go together).
 #include "eu_render_dev.h"
 
-#define EU_MULTI_MAXF 64     // facets per job (one mask bit each)
+#define EU_MULTI_MAXF 64     // facets per job with alpha compositing (one mask bit each); no limit otherwise
 #define EU_MULTI_KEEP 16     // facets whose coordinates are kept in LDS (3 KB each per workgroup)
 
 struct eu_multi_params {
@@ -480,7 +480,8 @@ extern "C" int eu_launch_render_multi_nch4(const eu_multi_params *p, int degree,
 extern "C" int eu_launch_render_multi(const void *pp, int degree, void *stream)
 {
   eu_multi_params p = *(const eu_multi_params *)pp;
-  if (p.nfct > EU_MULTI_MAXF) return -3;
+  // voronoi_syn and hdr_merge keep no per-facet state: any number of facets
+  if (p.nfct > EU_MULTI_MAXF && p.plus && !p.hdr) return -3;
   p.tiles_x = (p.width + EU_TILE_W - 1) / EU_TILE_W;
   p.tiles_y = (p.row_end - p.row_begin + EU_TILE_H - 1) / EU_TILE_H;
   if (p.tiles_x <= 0 || p.tiles_y <= 0) return 0;

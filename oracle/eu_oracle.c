@@ -1770,7 +1770,7 @@ static int mount_mask(const mount_t *m, const float *ray)
 /* EUO_LANES pixels that start at segment boundaries, like zimt::process.      */
 /* ------------------------------------------------------------------------ */
 
-#define EUO_MAX_FACETS 64
+#define EUO_MAX_FACETS 256
 
 typedef struct {
   int nfct, nch, plus;

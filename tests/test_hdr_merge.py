@@ -2,6 +2,8 @@
 sum of ALL facets of a job. CPU part: the oracle's restatement against an independent numpy
 model built from single-facet renders; GPU part (marked): the HIP multi-facet kernel against
 the oracle, bit for bit."""
+import math
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,22 @@ def test_hdr_merge_mixed_channel_counts_and_many_facets():
                                                   brighten=0.5 + 0.1 * k), o.container, 1, o.bc[0], o.bc[1]))
     a = ea.arguments(ea.SPHERICAL, 200, 100, 360.0, spline_degree=1, synopsis="hdr_merge")
     assert_bits(ea.render(a, gs20, 3), jobs.oracle_render(a, os20), "hdr_merge 20 facets")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("synopsis,nch", [("panorama", 3), ("panorama", 1), ("hdr_merge", 3), ("hdr_merge", 4)])
+def test_more_than_sixty_four_facets(synopsis, nch):
+    """voronoi_syn and hdr_merge keep no per-facet state on the device: 90 facets in one job (alpha
+    compositing - voronoi_syn_plus - stays at 64: one mask bit per facet)"""
+    os90, gs90 = [], []
+    for k in range(90):
+        img = jobs.synth_image(40, 40, nch, seed=300 + k)
+        kw = dict(yaw=4.0 * k, pitch=25.0 * math.sin(k), brighten=0.6 + 0.01 * k)
+        o = jobs.OracleSource(euo.RECTILINEAR, 40, 40, 40.0, img, 1, **kw)
+        os90.append(o)
+        gs90.append(ea.Source.adopt(ea.facet_spec(ea.RECTILINEAR, 40, 40, 40.0, nchannels=nch, **kw), o.container, 1, o.bc[0], o.bc[1]))
+    a = ea.arguments(ea.SPHERICAL, 240, 120, 360.0, spline_degree=1, synopsis=synopsis)
+    assert_bits(ea.render(a, gs90, nch), jobs.oracle_render(a, os90), f"90 facets {synopsis} nch {nch}")
+    if nch == 4:
+        with pytest.raises(Exception):
+            ea.render(ea.arguments(ea.SPHERICAL, 240, 120, 360.0, spline_degree=1), gs90, nch)
