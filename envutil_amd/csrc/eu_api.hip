@@ -833,20 +833,8 @@ int eu_hip_source_load(const eu_facet *fct, const float *pixels, int spline_degr
   source_bcs(fct, &bc0, &bc1);
   eu_source *s = nullptr;
   if ((rc = new_source(fct, spline_degree, bc0, bc1, support_min, tile_size, &s))) return rc;
-  if (!is_cube(fct->projection)) {
-    // The device braces all frame slices at once from the core; zimt fills them one by one,
-    // outward, and for an image narrower than the spline's frame a slice is copied from
-    // slices filled before it (brace.h:134-330). Such images (a few pixels wide) are left
-    // to the host: prefilter there and hand the container over with eu_hip_source_adopt.
-    for (int a = 0; a < 2; a++) {
-      const long long m = s->geom.core[a], fr = std::max(s->geom.left[a], s->geom.right[a]);
-      if (m != 1 && m < fr + 1) {
-        (void)hipFree(s->dev);
-        delete s;
-        return fail(EU_ERR_UNSUPPORTED, "source narrower than the spline's frame: prefilter on the host and adopt");
-      }
-    }
-  }
+  // (a core narrower than the spline's frame on an axis is braced slice by slice in zimt's order,
+  // eu_setup.hip: brace_seq_kernel; such a full-sphere image - at most 4 x 2 pixels - is refused below)
   const int nch = s->nch;
   hipError_t e = hipSuccess;
   if (is_cube(fct->projection)) {
@@ -877,6 +865,14 @@ int eu_hip_source_load(const eu_facet *fct, const float *pixels, int spline_degr
       // two-axis periodic scheme, everything else bspline::prefilter()
       int spherical = fct->projection == EU_SPHERICAL && std::fabs(fct->hfov - 2.0 * M_PI) < .000001
                       && fct->width == 2 * fct->height;
+      for (int a = 0; a < 2 && spherical; a++) {
+        const long long m = gm.core[a], fr = std::max(gm.left[a], gm.right[a]);
+        if (m != 1 && m < fr + 1) {
+          (void)hipFree(s->dev);
+          delete s;
+          return fail(EU_ERR_UNSUPPORTED, "full-sphere source narrower than the spline's frame: prefilter on the host and adopt");
+        }
+      }
       rc = eu_launch_prefilter(s->dev, &s->geom, nch, bc0, bc1, prefilter_degree, spherical, g.stream);
       e = hipStreamSynchronize(g.stream);
     }

@@ -747,6 +747,52 @@ __global__ void mirror_around_kernel(float *ir, int nch, long long F, long long 
   }
 }
 
+// The same bracing in zimt's own ORDER (brace.h:134-330): slice after slice outward, left and right
+// alternating, each slice from the slice the rule names AS IT STANDS - for a core narrower than the
+// frame the rule runs into slices filled a step before, which the all-at-once kernel above cannot
+// reproduce. One thread per line along the axis; used for such cores only (a few pixels wide).
+__global__ void brace_seq_kernel(float *data, long long sx, long long sy, int nch, int axis, int bc,
+                                 long long lsz, long long rsz)
+{
+  const long long w = axis == 0 ? sx : sy, other = axis == 0 ? sy : sx;
+  const long long m = w - lsz - rsz;
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= other * nch) return;
+  const int c = (int)(t % nch);
+  const long long o = t / nch;
+  auto at = [&](long long a) -> float * {
+    return axis == 0 ? data + (o * sx + a) * nch + c : data + (a * sx + o) * nch + c;
+  };
+  if (m == 1) {
+    for (long long i = 0; i < w; i++) if (i != lsz) *at(i) = *at(lsz);
+    return;
+  }
+  const long long l0 = lsz - 1, r0 = lsz + m, lp = l0 + 1, rp = r0 - 1, l1 = -1, r1 = w;
+  long long lt = l0, rt = r0, ls = 0, rs = 0, ds = 1;
+  switch (bc) {
+    case EU_BC_PERIODIC: ls = l0 + m; rs = r0 - m; ds = -1; break;
+    case EU_BC_NATURAL:
+    case EU_BC_MIRROR:   ls = l0 + 2; rs = r0 - 2; break;
+    default:             ls = l0 + 1; rs = r0 - 1; break;     // CONSTANT, REFLECT (ZEROPAD: unused)
+  }
+  for (long long i = lsz > rsz ? lsz : rsz; i > 0; --i) {
+    if (lt > l1) {
+      if (bc == EU_BC_NATURAL) { const float a = *at(lp), b = *at(ls); *at(lt) = a + a - b; }
+      else if (bc == EU_BC_CONSTANT) *at(lt) = *at(lp);
+      else if (bc == EU_BC_ZEROPAD) *at(lt) = 0.0f;
+      else *at(lt) = *at(ls);
+      --lt; ls += ds;
+    }
+    if (rt < r1) {
+      if (bc == EU_BC_NATURAL) { const float a = *at(rp), b = *at(rs); *at(rt) = a + a - b; }
+      else if (bc == EU_BC_CONSTANT) *at(rt) = *at(rp);
+      else if (bc == EU_BC_ZEROPAD) *at(rt) = 0.0f;
+      else *at(rt) = *at(rs);
+      ++rt; rs -= ds;
+    }
+  }
+}
+
 __device__ __forceinline__ float mirror_gate(float c, float lower, float upper)
 {
   float cc = c - lower, w = upper - lower;
@@ -885,6 +931,21 @@ __global__ void fill_tie_kernel(float *ir, int nch, int face, int stripe, long l
 }
 
 inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// frame of one axis: all slices at once, or - a core narrower than the frame - in zimt's order
+void launch_brace(float *container, long long SX, long long SY, int nch, int axis, int bc, long long lsz,
+                  long long rsz, hipStream_t st)
+{
+  const long long len = axis == 0 ? SX : SY, other = axis == 0 ? SY : SX, m = len - lsz - rsz;
+  if (lsz + rsz <= 0) return;
+  if (m != 1 && m < (lsz > rsz ? lsz : rsz) + 1) {
+    hipLaunchKernelGGL(brace_seq_kernel, dim3(blocks_for(other * nch, 256)), dim3(256), 0, st, container, SX, SY,
+                       nch, axis, bc, lsz, rsz);
+    return;
+  }
+  hipLaunchKernelGGL(brace_kernel, dim3(blocks_for((lsz + rsz) * other * nch, 256)), dim3(256), 0, st, container,
+                     SX, SY, nch, axis, bc, lsz, rsz);
+}
 
 // EU_HIP_IIR_STREAM=0: the one-thread-per-line kernels only (the form the streamed ones are
 // checked against on the device, tests/test_gpu_prefilter_stream.py)
@@ -1045,14 +1106,8 @@ extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int 
     iir_dev f1 = make_iir(bc1, degree, (long double)FLT_EPSILON, H);
     launch_filter_cols(f1, core, W * nch, SX * nch, (int)H, st);
   }
-  long long nb0 = (g->left[0] + g->right[0]) * SY * nch;
-  if (nb0 > 0)
-    hipLaunchKernelGGL(brace_kernel, dim3(blocks_for(nb0, 256)), dim3(256), 0, st, container, SX,
-                       SY, nch, 0, bc0, (long long)g->left[0], (long long)g->right[0]);
-  long long nb1 = (g->left[1] + g->right[1]) * SX * nch;
-  if (nb1 > 0)
-    hipLaunchKernelGGL(brace_kernel, dim3(blocks_for(nb1, 256)), dim3(256), 0, st, container, SX,
-                       SY, nch, 1, bc1, (long long)g->left[1], (long long)g->right[1]);
+  launch_brace(container, SX, SY, nch, 0, bc0, (long long)g->left[0], (long long)g->right[0], st);
+  launch_brace(container, SX, SY, nch, 1, bc1, (long long)g->left[1], (long long)g->right[1], st);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

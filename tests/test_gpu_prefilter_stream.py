@@ -99,3 +99,17 @@ def test_large_source_streamed_equals_generic():
         b = g2.download()
         g2.release()
     same(a, b, "8192x4096 streamed vs one thread per line")
+
+
+@pytest.mark.parametrize("sw,sh", [(2, 40), (3, 50), (4, 33), (40, 2), (50, 3), (3, 3), (2, 2), (5, 4), (1, 30), (30, 1)])
+@pytest.mark.parametrize("degree", [2, 3, 5, 7])
+def test_sources_narrower_than_the_frame(sw, sh, degree):
+    """a core of 2-4 pixels on an axis: zimt braces slice by slice outward and reads slices it filled a
+    step before (brace.h:134-330); the device does the same for such cores (brace_seq_kernel)"""
+    for sprj, hfov in ((euo.RECTILINEAR, 60.0), (euo.CYLINDRICAL, 360.0), (euo.SPHERICAL, 90.0)):
+        for nch in (1, 3):
+            img = jobs.synth_image(sw, sh, nch, seed=sw * 31 + sh)
+            g = ea.Source.load(ea.facet_spec(sprj, sw, sh, hfov, nchannels=nch), img, degree)
+            o = jobs.OracleSource(sprj, sw, sh, hfov, img, degree)
+            same(g.download(), o.container, f"narrow {sw}x{sh}x{nch} projection {sprj} degree {degree}")
+            g.release()
