@@ -88,6 +88,7 @@ extern "C" int eu_launch_diag(const eu_render_params *pp, unsigned long long *st
                               void *stream)
 {
   eu_render_params p = *pp;
+  if (p.form == EU_FORM_GENERIC) return -1;     // the phase stamps are for the ordinary steppers
   p.tiles_x = (p.width + EU_TILE_W - 1) / EU_TILE_W;
   p.tiles_y = (p.row_end - p.row_begin + EU_TILE_H - 1) / EU_TILE_H;
   hipLaunchKernelGGL(eu_diag_kernel, dim3((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), dim3(256), 0,

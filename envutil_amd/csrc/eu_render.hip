@@ -33,7 +33,9 @@
 // the kernel
 // ---------------------------------------------------------------------------
 
-template <int NCH, int DEG, bool TWINE>
+// GEN: the job's stepper is the generic one (EU_FORM_GENERIC: a facet with translation, --single); only the
+// run-time-degree variants are instantiated with it
+template <int NCH, int DEG, bool TWINE, bool GEN = false>
 __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p)
 {
   const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
   const float *rowt = p.row + (long long)eu_frame_row(y, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
   const float *col0 = p.col, *col1 = p.col + p.width;
   float rx, ry, rz;
-  eu_stepper(p, col0, col1, rowt, x, rx, ry, rz);
+  eu_stepper<GEN>(p, col0, col1, rowt, x, rx, ry, rz);
 
   float *dst = p.out + (long long)(y - p.row_begin) * p.out_stride;
   if (p.stage == 1) {
@@ -75,8 +77,8 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
     } else {
       const float *col2 = p.col + 2 * p.width, *col3 = p.col + 3 * p.width;
       float ax, ay, az, bx, by, bz;
-      eu_stepper(p, col2, col3, rowt, x, ax, ay, az);
-      eu_stepper(p, col0, col1, rowt + EU_ROW_VARIANT, x, bx, by, bz);
+      eu_stepper<GEN>(p, col2, col3, rowt, x, ax, ay, az);
+      eu_stepper<GEN>(p, col0, col1, rowt + EU_ROW_VARIANT, x, bx, by, bz);
       float dxx = ax - rx, dxy = ay - ry, dxz = az - rz;
       float dyx = bx - rx, dyy = by - ry, dyz = bz - rz;
       for (int k = 0; k < p.ntaps; k++) {
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p
     // deriv_stepper (stepper.h:1591-1715) + twine_t::eval (twining.h:128-263)
     const float *col2 = p.col + 2 * p.width, *col3 = p.col + 3 * p.width;
     float ax, ay, az, bx, by, bz;
-    eu_stepper(p, col2, col3, rowt, x, ax, ay, az);          // r10: x-biased
-    eu_stepper(p, col0, col1, rowt + EU_ROW_VARIANT, x, bx, by, bz);      // r01: y-biased
+    eu_stepper<GEN>(p, col2, col3, rowt, x, ax, ay, az);          // r10: x-biased
+    eu_stepper<GEN>(p, col0, col1, rowt + EU_ROW_VARIANT, x, bx, by, bz);      // r01: y-biased
     float dxx = ax - rx, dxy = ay - ry, dxz = az - rz;
     float dyx = bx - rx, dyy = by - ry, dyz = bz - rz;
 #pragma unroll
@@ -242,6 +244,13 @@ template <int NCH, int DEG>
 static hipError_t launch_nd(const eu_render_params &p, hipStream_t st)
 {
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), block(256);
+  if (p.form == EU_FORM_GENERIC) {
+    if constexpr (DEG == -1) {
+      if (p.twine) hipLaunchKernelGGL((eu_render_kernel<NCH, -1, true, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((eu_render_kernel<NCH, -1, false, true>), grid, block, 0, st, p);
+    }
+    return hipGetLastError();
+  }
   if (p.twine) hipLaunchKernelGGL((eu_render_kernel<NCH, DEG, true>), grid, block, 0, st, p);
   else if (DEG >= 1 && p.stage == 0 && !p.direct && p.nch_out == p.nch) {
     if constexpr (DEG >= 1) hipLaunchKernelGGL((eu_render_lds_kernel<NCH, DEG>), grid, block, 0, st, p);
@@ -253,6 +262,7 @@ static hipError_t launch_nd(const eu_render_params &p, hipStream_t st)
 template <int NCH>
 static hipError_t launch_n(const eu_render_params &p, hipStream_t st)
 {
+  if (p.form == EU_FORM_GENERIC) return launch_nd<NCH, -1>(p, st);   // generic stepper: run-time-degree kernels only
   switch (p.src.degree) {
     case 0: return launch_nd<NCH, 0>(p, st);
     case 1: return launch_nd<NCH, 1>(p, st);

@@ -568,6 +568,9 @@ __device__ __forceinline__ float eu_inv_lcp(const eu_inv_planar &q, double x)
   return sum + 1.0f;
 }
 
+// Only kernels instantiated with GEN = true contain this path (eu_stepper<GEN>): inlined into the ordinary
+// kernels - rare as it is, and with double arithmetic in it - it cost the multi-facet kernel 48 bytes of
+// scratch per thread and 14 % of config 5; as a call it raised every kernel's register count to its own.
 __device__ __forceinline__ void eu_generic_ray(const eu_generic &g, const eu_inv_planar *inv, float p0,
                                                float p1, float &rx, float &ry, float &rz)
 {
@@ -605,13 +608,16 @@ __device__ __forceinline__ void eu_generic_ray(const eu_generic &g, const eu_inv
 
 // full stepper: tables -> ray, with the normalisation flavour of the stepper. gen / raw: the facet's
 // eu_generic and the raw planar x column, for form == EU_FORM_GENERIC
+template <bool GEN = false>
 __device__ __forceinline__ void eu_stepper(int form, int norm_mode, const float *colA,
                                            const float *colB, const float *rowt, int x,
                                            float &rx, float &ry, float &rz,
                                            const eu_generic *gen = nullptr, const float *raw = nullptr,
                                            const eu_inv_planar *inv = nullptr)
 {
-  if (form == EU_FORM_GENERIC) eu_generic_ray(*gen, inv, raw[x], rowt[9], rx, ry, rz);
+  if (GEN && form == EU_FORM_GENERIC) {
+    if constexpr (GEN) eu_generic_ray(*gen, inv, raw[x], rowt[9], rx, ry, rz);
+  }
   else eu_ray(form, rowt, colA[x], colB[x], rx, ry, rz);
   if (norm_mode == EU_NORM_DIV) {
     float n = eu_norm3(rx, ry, rz);
@@ -654,14 +660,19 @@ static inline int eu_xcd_grid(int tiles_x, int tiles_y, int unit_rows)
 
 #define EU_UNIT_ROWS 8
 
+template <bool GEN = false>
 __device__ __forceinline__ void eu_stepper(const eu_render_params &p, const float *colA,
                                            const float *colB, const float *rowt, int x,
                                            float &rx, float &ry, float &rz)
 {
-  // colA is p.col (r00, r01) or p.col + 2 * width (r10): the raw planar column goes with it
-  const float *raw = p.col + (colA == p.col ? 4 : 5) * (long long)p.width;
-  eu_stepper(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz, &p.gen, raw,
-             (p.inv.shear | p.inv.shift | p.inv.lcp) ? &p.inv : nullptr);
+  if constexpr (GEN) {
+    // colA is p.col (r00, r01) or p.col + 2 * width (r10): the raw planar column goes with it
+    const float *raw = p.col + (colA == p.col ? 4 : 5) * (long long)p.width;
+    eu_stepper<true>(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz, &p.gen, raw,
+                     (p.inv.shear | p.inv.shift | p.inv.lcp) ? &p.inv : nullptr);
+  } else {
+    eu_stepper<false>(p.form, p.norm_mode, colA, colB, rowt, x, rx, ry, rz);
+  }
 }
 
 #endif

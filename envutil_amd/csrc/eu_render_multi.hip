@@ -45,33 +45,37 @@ struct eu_multi_params {
 struct eu_pix { int x, y; };
 
 // ray of facet f for this pixel; variant 0: r00, 1: x-biased, 2: y-biased
+template <bool GEN>
 __device__ __forceinline__ void eu_multi_ray(const eu_multi_params &p, int f, int variant,
                                              const eu_pix &px, float &rx, float &ry, float &rz)
 {
   const float *rowt = p.row + ((long long)f * p.height + eu_frame_row(px.y, p.band_shift, p.band_count, p.band_index)) * EU_ROW_FLOATS
                       + (variant == 2 ? EU_ROW_VARIANT : 0);
   const float *ca = variant == 1 ? p.col + 2 * p.width : p.col;
-  if (p.gen && p.gen[f].on) {               // f is wave-uniform
-    // generic_stepper<float, LANES, true>: the ray is normalised (stepper.h:431-434)
-    eu_stepper(EU_FORM_GENERIC, EU_NORM_DIV, ca, ca, rowt, px.x, rx, ry, rz, &p.gen[f],
-               p.col + (variant == 1 ? 5 : 4) * (long long)p.width,
-               (p.inv.shear | p.inv.shift | p.inv.lcp) ? &p.inv : nullptr);
-    return;
+  if constexpr (GEN) {
+    if (p.gen[f].on) {                      // f is wave-uniform
+      // generic_stepper<float, LANES, true>: the ray is normalised (stepper.h:431-434)
+      eu_stepper<true>(EU_FORM_GENERIC, EU_NORM_DIV, ca, ca, rowt, px.x, rx, ry, rz, &p.gen[f],
+                       p.col + (variant == 1 ? 5 : 4) * (long long)p.width,
+                       (p.inv.shear | p.inv.shift | p.inv.lcp) ? &p.inv : nullptr);
+      return;
+    }
   }
-  eu_stepper(p.form, p.norm_mode, ca, ca + p.width, rowt, px.x, rx, ry, rz);
+  eu_stepper<false>(p.form, p.norm_mode, ca, ca + p.width, rowt, px.x, rx, ry, rz);
 }
 
 // the ray the synopsis sees for facet f: the stepper's, or the twining tap's
 // p0 + cx * du + cy * dv (payload.cc:669-675)
+template <bool GEN>
 __device__ __forceinline__ void eu_syn_ray(const eu_multi_params &p, int f, const eu_pix &px,
                                            bool tap, float cx, float cy, float &rx, float &ry,
                                            float &rz)
 {
-  eu_multi_ray(p, f, 0, px, rx, ry, rz);
+  eu_multi_ray<GEN>(p, f, 0, px, rx, ry, rz);
   if (tap) {
     float ax, ay, az, bx, by, bz;
-    eu_multi_ray(p, f, 1, px, ax, ay, az);
-    eu_multi_ray(p, f, 2, px, bx, by, bz);
+    eu_multi_ray<GEN>(p, f, 1, px, ax, ay, az);
+    eu_multi_ray<GEN>(p, f, 2, px, bx, by, bz);
     float dux = ax - rx, duy = ay - ry, duz = az - rz;
     float dvx = bx - rx, dvy = by - ry, dvz = bz - rz;
     rx = rx + cx * dux + cy * dvx;
@@ -123,7 +127,7 @@ __device__ __forceinline__ void eu_env_facet(const eu_src_dev &s, bool hit, floa
 
 // evaluate facet `want` (wave-divergent, -1: none) for this lane; hitm: the
 // facets this lane's ray hits (bit per facet)
-template <int NCH, int DEG>
+template <int NCH, int DEG, bool GEN>
 __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want, const eu_pix &px,
                                               bool tap, float cx, float cy, const eu_slots &sl,
                                               unsigned long long hitm, float *out)
@@ -146,7 +150,7 @@ __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want
       } else {
         float rx, ry, rz;
         int face;
-        eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+        eu_syn_ray<GEN>(p, f, px, tap, cx, cy, rx, ry, rz);
         hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
       }
       eu_env_facet<NCH, DEG>(s, hit, sx, sy, out);
@@ -156,7 +160,7 @@ __device__ __forceinline__ void eu_eval_facet(const eu_multi_params &p, int want
 }
 
 // one synopsis evaluation for this lane
-template <int NCH, int DEG, bool PLUS>
+template <int NCH, int DEG, bool PLUS, bool GEN>
 __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_pix &px,
                                             bool live, bool tap, float cx, float cy,
                                             const eu_slots &sl, float *out)
@@ -173,7 +177,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
     for (int f = 0; f < nf; f++) {
       float rx, ry, rz, sx = 0.0f, sy = 0.0f;
       int face;
-      eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+      eu_syn_ray<GEN>(p, f, px, tap, cx, cy, rx, ry, rz);
       const eu_src_dev &s = p.srcs[f];
       const bool masked = !s.mask_all;        // wave-uniform
       bool hit = true;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
         if (!have) {
           float rx, ry, rz;
           int face;
-          eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+          eu_syn_ray<GEN>(p, f, px, tap, cx, cy, rx, ry, rz);
           hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
         }
         eu_env_facet<NCH, DEG>(s, hit, sx, sy, out);
@@ -225,7 +229,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
     for (int f = 0; f < nf; f++) {
       float rx, ry, rz, sx = 0.0f, sy = 0.0f;
       int face;
-      eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+      eu_syn_ray<GEN>(p, f, px, tap, cx, cy, rx, ry, rz);
       const eu_src_dev &s = p.srcs[f];
       bool hit = true;
       if (!s.mask_all) {
@@ -265,7 +269,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       unsigned long long tm = __ballot(live && top == next_best);
       bool all_top = !done && ((unsigned)(tm >> (16 * grp)) & 0xffffu) == live_g;
       float help[NCH];
-      eu_eval_facet<NCH, DEG>(p, all_top ? next_best : -1, px, tap, cx, cy, sl, hitm, help);
+      eu_eval_facet<NCH, DEG, GEN>(p, all_top ? next_best : -1, px, tap, cx, cy, sl, hitm, help);
       unsigned long long om = __ballot(all_top && help[NCH - 1] >= 1.0f);
       bool opaque = all_top && ((unsigned)(om >> (16 * grp)) & 0xffffu) == live_g;
       if (opaque) {
@@ -281,7 +285,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       int f = done ? -1 : pick(used);
       if (!__ballot(f >= 0)) break;
       float help[NCH];
-      eu_eval_facet<NCH, DEG>(p, f, px, tap, cx, cy, sl, hitm, help);
+      eu_eval_facet<NCH, DEG, GEN>(p, f, px, tap, cx, cy, sl, hitm, help);
       if (f >= 0) {
         used |= 1ull << f;
         if (layer == 0) {
@@ -313,7 +317,7 @@ __device__ __forceinline__ float eu_std_max(float a, float b) { return a < b ? b
 // _hdr_merge_syn::operator() (envutil_payload.cc:1500-1622): EVERY facet is evaluated - a miss is a
 // zero pixel and takes part with the quality a zero pixel has -, quality-weighted sum, normalised.
 // The one per-VECTOR decision (all_of(alpha == 0) -> quality 0) is a ballot over the lane's group of 16.
-template <int NCH, int DEG>
+template <int NCH, int DEG, bool GEN>
 __device__ __forceinline__ void eu_synopsis_hdr(const eu_multi_params &p, const eu_pix &px, bool live,
                                                 bool tap, float cx, float cy, float *out)
 {
@@ -328,7 +332,7 @@ __device__ __forceinline__ void eu_synopsis_hdr(const eu_multi_params &p, const 
   for (int f = 0; f < p.nfct; f++) {
     float rx, ry, rz, sx = 0.0f, sy = 0.0f;
     int face;
-    eu_syn_ray(p, f, px, tap, cx, cy, rx, ry, rz);
+    eu_syn_ray<GEN>(p, f, px, tap, cx, cy, rx, ry, rz);
     const eu_src_dev &s = p.srcs[f];
     bool hit = true, any = true;
     if (!s.mask_all) {
@@ -390,7 +394,9 @@ __device__ __forceinline__ void eu_synopsis_hdr(const eu_multi_params &p, const 
 #endif
 #define EU_MULTI_OCC __attribute__((amdgpu_waves_per_eu(EU_MULTI_WAVES, EU_MULTI_WAVES)))
 
-template <int NCH, int DEG, bool PLUS, bool HDR = false>
+// GEN: some facet of the job is stepped by generic_stepper (translation, --single); only the run-time-degree
+// variants are instantiated with it
+template <int NCH, int DEG, bool PLUS, bool HDR = false, bool GEN = false>
 __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const eu_multi_params p)
 {
   extern __shared__ float eu_dyn_lds[];
@@ -412,16 +418,16 @@ __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const
   sl.sy = sl.sx + p.nfct * 256;
   float out[NCH];
   if (!p.twine) {
-    if constexpr (HDR) eu_synopsis_hdr<NCH, DEG>(p, px, live, false, 0.0f, 0.0f, out);
-    else eu_synopsis<NCH, DEG, PLUS>(p, px, live, false, 0.0f, 0.0f, sl, out);
+    if constexpr (HDR) eu_synopsis_hdr<NCH, DEG, GEN>(p, px, live, false, 0.0f, 0.0f, out);
+    else eu_synopsis<NCH, DEG, PLUS, GEN>(p, px, live, false, 0.0f, 0.0f, sl, out);
   } else {
 #pragma unroll
     for (int c = 0; c < NCH; c++) out[c] = 0.0f;
     for (int k = 0; k < p.ntaps; k++) {
       const float cx = p.taps[3 * k], cy = p.taps[3 * k + 1], cw = p.taps[3 * k + 2];
       float help[NCH];
-      if constexpr (HDR) eu_synopsis_hdr<NCH, DEG>(p, px, live, true, cx, cy, help);
-      else eu_synopsis<NCH, DEG, PLUS>(p, px, live, true, cx, cy, sl, help);
+      if constexpr (HDR) eu_synopsis_hdr<NCH, DEG, GEN>(p, px, live, true, cx, cy, help);
+      else eu_synopsis<NCH, DEG, PLUS, GEN>(p, px, live, true, cx, cy, sl, help);
 #pragma unroll
       for (int c = 0; c < NCH; c++) out[c] = out[c] + cw * help[c];
     }
@@ -437,6 +443,11 @@ static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
   // alpha compositing keeps z (and, for up to EU_MULTI_KEEP facets, the source
   // coordinate) of every facet per thread in LDS
   const size_t lds = PLUS && !p.hdr ? (size_t)(p.nfct <= EU_MULTI_KEEP ? 3 : 1) * p.nfct * 256 * sizeof(float) : 0;
+  if (p.gen) {
+    if (p.hdr) hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, PLUS, true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, PLUS, false, true>), grid, block, lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (p.hdr) {
     switch (degree) {
       case 0: hipLaunchKernelGGL((eu_render_multi_kernel<NCH, 0, PLUS, true>), grid, block, lds, st, p); break;
