@@ -189,11 +189,15 @@ def main():
     nsrcs = len(sources)
     tgt = args.target(nch, r0, r1, 0, band)
 
+    # the steps run on a stream of their own, so that HIP events on THAT stream bracket the timed steps
+    # (torch.cuda.Event sees only the stream it is recorded on)
+    st = torch.cuda.Stream(device=dev)
+
     def step():
         if r1 <= r0:
             return          # a rank without rows (more ranks than row units) only joins the collectives
         rc = ea.lib().eu_hip_render(C.byref(tgt), srcs, nsrcs, C.c_void_p(out.data_ptr()),
-                                    tw * nch * 4, 1, None)
+                                    tw * nch * 4, 1, C.c_void_p(st.cuda_stream))
         if rc:
             raise SystemExit("render failed: " + ea.lib().eu_hip_last_error().decode())
 
@@ -203,19 +207,29 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # kernel-only time of the same launches with HIP events on the library's stream, BEFORE the steps: it
+    # builds the plan and brings the clocks up (after the set-up's idle gaps the first ~10 launches of a
+    # process run slower, tools/_step_overhead.py); the timed steps below carry events of their own
+    kernel_ms_pre = ea.render_timed(args, sources, out.data_ptr(), max(a.steps, 20), nch, r0, r1, band) if r1 > r0 else 0.0
+
     for _ in range(a.warmup):
         step()
     sync_all()
     ea.lib().eu_hip_launch_count.restype = C.c_ulonglong
     launches0 = ea.lib().eu_hip_launch_count()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(st)
     for _ in range(a.steps):
         step()
+    ev1.record(st)
     ea.lib().eu_hip_sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # GPU time of exactly the timed steps, per step, on the stream they were launched on
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps if r1 > r0 else 0.0
     launches_per_step = (ea.lib().eu_hip_launch_count() - launches0) / a.steps if nsrcs == 1 else 1
     if dist is not None:
         tmax = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
@@ -247,8 +261,6 @@ def main():
             del whole
         del frame
 
-    # ---- kernel-only time with HIP events on the kernel's stream ------------
-    kernel_ms = ea.render_timed(args, sources, out.data_ptr(), max(a.steps, 5), nch, r0, r1, band) if r1 > r0 else 0.0
 
     # ---- the boundary with HOST buffers (never `value`): pixels in, pixels out ----
     # load = H2D of the source + prefilter/brace on the device; render_to_host =
@@ -363,6 +375,8 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
+                     "kernel_ms_note": "HIP events on the launch stream around the timed steps, per step",
+                     "kernel_ms_pre": round(kernel_ms_pre, 4),
                      "launches_per_step": launches_per_step,
                      "algorithmic_bytes": alg_bytes},
     }
