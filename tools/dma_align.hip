@@ -1,3 +1,4 @@
+// usage: hipcc -O2 --offload-arch=gfx950 tools/dma_align.hip -o /tmp/dma_align && /tmp/dma_align   (round 2: every 4-byte alignment, partial EXEC - all correct)
 // LDS-DMA (global_load_lds_dwordx4) with global addresses of every 4-byte alignment: what lands in LDS?
 #include <hip/hip_runtime.h>
 #include <cstdio>
