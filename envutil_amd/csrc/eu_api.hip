@@ -379,7 +379,7 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
 {
   if (!t || !srcs || !out_dev) return fail(EU_ERR_ARGUMENT, "null argument");
   if (nsrc != 1)
-    return fail(EU_ERR_UNSUPPORTED, "multi-facet synopsis (voronoi_syn) not built yet: nsrc must be 1");
+    return fail(EU_ERR_ARGUMENT, "build_params takes one source (several facets go through build_multi)");
   eu_source *s = srcs[0];
   if (!s) return fail(EU_ERR_HANDLE, "null source");
   { int rc0 = check_target(t); if (rc0) return rc0; }
