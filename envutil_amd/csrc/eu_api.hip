@@ -484,9 +484,6 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
                 size_t row_stride_bytes, multi_params *p, int *degree)
 {
   { int rc0 = check_target(t); if (rc0) return rc0; }
-  // voronoi_syn_plus keeps one mask bit per facet; voronoi_syn (1 / 3 channels) and hdr_merge keep nothing
-  if (nsrc > 64 && (t->nchannels == 2 || t->nchannels == 4) && t->synopsis != EU_SYN_HDR_MERGE)
-    return fail(EU_ERR_UNSUPPORTED, "more than 64 facets in a job with alpha compositing");
   const eu_source *s0 = srcs[0];
   for (int f = 0; f < nsrc; f++) {
     if (!srcs[f]) return fail(EU_ERR_HANDLE, "null source");

@@ -23,7 +23,7 @@
 // loop (readlane makes the index uniform, the lanes that want it go together).
 #include "eu_render_dev.h"
 
-#define EU_MULTI_MAXF 64     // facets per job with alpha compositing (one mask bit each); no limit otherwise
+#define EU_MULTI_MAXF 64     // facets per job the mask-based alpha compositing takes (one bit each); beyond: eu_synopsis_big
 #define EU_MULTI_KEEP 16     // facets whose coordinates are kept in LDS (3 KB each per workgroup)
 
 struct eu_multi_params {
@@ -53,7 +53,7 @@ __device__ __forceinline__ void eu_multi_ray(const eu_multi_params &p, int f, in
                       + (variant == 2 ? EU_ROW_VARIANT : 0);
   const float *ca = variant == 1 ? p.col + 2 * p.width : p.col;
   if constexpr (GEN) {
-    if (p.gen[f].on) {                      // f is wave-uniform
+    if (p.gen && p.gen[f].on) {             // f is wave-uniform
       // generic_stepper<float, LANES, true>: the ray is normalised (stepper.h:431-434)
       eu_stepper<true>(EU_FORM_GENERIC, EU_NORM_DIV, ca, ca, rowt, px.x, rx, ry, rz, &p.gen[f],
                        p.col + (variant == 1 ? 5 : 4) * (long long)p.width,
@@ -302,6 +302,90 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
   }
 }
 
+// _voronoi_syn_plus for MORE facets than there are mask bits: nothing is kept per facet. A pass over all
+// facets finds this lane's nearest valid facet BEHIND the layer composited last - (z, facet) smaller in
+// the order the reference's layer list has (z descending, the earlier facet first among equals) - by
+// recomputing every facet's ray, hit test and z score; one such pass per layer. Slow (facets x layers)
+// and without limit; jobs of up to 64 facets use eu_synopsis.
+template <int NCH, int DEG, bool GEN>
+__device__ __forceinline__ void eu_synopsis_big(const eu_multi_params &p, const eu_pix &px, bool live,
+                                                bool tap, float cx, float cy, const eu_slots &sl, float *out)
+{
+  const int nf = p.nfct;
+  const int grp = (threadIdx.x & 63) >> 4;
+  const unsigned live_g = (unsigned)(__ballot(live) >> (16 * grp)) & 0xffffu;
+  // the nearest valid facet behind (lz, lf); first = true: the nearest of all. Also next_best of the
+  // lane's vector: the last facet valid for any of its lanes
+  int next_best = -1;
+  auto pick = [&](bool first, float lz, int lf, float &bz) {
+    int best = -1;
+    bz = 0.0f;
+#pragma unroll 1
+    for (int f = 0; f < nf; f++) {
+      float rx, ry, rz, sx = 0.0f, sy = 0.0f;
+      int face;
+      eu_syn_ray<GEN>(p, f, px, tap, cx, cy, rx, ry, rz);
+      const eu_src_dev &s = p.srcs[f];
+      bool hit = true;
+      if (!s.mask_all) {
+        const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+        hit = false;
+        if (__ballot(maybe)) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+      }
+      const bool v = hit && live;
+      if (first) {
+        const unsigned long long bm = __ballot(v);
+        if ((unsigned)(bm >> (16 * grp)) & 0xffffu) next_best = f;
+      }
+      const float z = rz * s.recip_step;
+      const bool behind = first || z < lz || (z == lz && f > lf);
+      if (v && behind && (best < 0 || z > bz)) { best = f; bz = z; }
+    }
+    return best;
+  };
+  float tz;
+  const int top = pick(true, 0.0f, -1, tz);
+#pragma unroll
+  for (int c = 0; c < NCH; c++) out[c] = 0.0f;
+  bool done = !live;
+  if (next_best < 0) done = true;
+  {
+    unsigned long long tm = __ballot(live && top == next_best);
+    bool all_top = !done && ((unsigned)(tm >> (16 * grp)) & 0xffffu) == live_g;
+    float help[NCH];
+    eu_eval_facet<NCH, DEG, GEN>(p, all_top ? next_best : -1, px, tap, cx, cy, sl, 0ull, help);
+    unsigned long long om = __ballot(all_top && help[NCH - 1] >= 1.0f);
+    bool opaque = all_top && ((unsigned)(om >> (16 * grp)) & 0xffffu) == live_g;
+    if (opaque) {
+#pragma unroll
+      for (int c = 0; c < NCH; c++) out[c] = help[c];
+      done = true;
+    }
+  }
+  int f = done ? -1 : top;
+  float fz = tz;
+  int layer = 0;
+  while (true) {
+    if (!__ballot(f >= 0)) break;
+    float help[NCH];
+    eu_eval_facet<NCH, DEG, GEN>(p, f, px, tap, cx, cy, sl, 0ull, help);
+    if (f >= 0) {
+      if (layer == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) out[c] = help[c];
+      } else {
+        const float a = out[NCH - 1];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) out[c] = out[c] + (1.0f - a) * help[c];
+      }
+      layer++;
+    }
+    float nz;
+    const int nxt = pick(false, fz, f >= 0 ? f : 0x7fffffff, nz);     // uniform control flow: every lane runs the pass
+    if (f >= 0) { f = nxt; fz = nz; }
+  }
+}
+
 // _hdr_merge_syn::get_quality for a grey value (envutil_payload.cc:1388-1446); kind 0 LOW, 1 MIDDLE, 2 HIGH
 __device__ __forceinline__ float eu_hdr_quality(float grey, float optimum, int kind)
 {
@@ -396,7 +480,8 @@ __device__ __forceinline__ void eu_synopsis_hdr(const eu_multi_params &p, const 
 
 // GEN: some facet of the job is stepped by generic_stepper (translation, --single); only the run-time-degree
 // variants are instantiated with it
-template <int NCH, int DEG, bool PLUS, bool HDR = false, bool GEN = false>
+// BIG: alpha compositing of more than 64 facets (eu_synopsis_big)
+template <int NCH, int DEG, bool PLUS, bool HDR = false, bool GEN = false, bool BIG = false>
 __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const eu_multi_params p)
 {
   extern __shared__ float eu_dyn_lds[];
@@ -419,6 +504,7 @@ __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const
   float out[NCH];
   if (!p.twine) {
     if constexpr (HDR) eu_synopsis_hdr<NCH, DEG, GEN>(p, px, live, false, 0.0f, 0.0f, out);
+    else if constexpr (BIG) eu_synopsis_big<NCH, DEG, GEN>(p, px, live, false, 0.0f, 0.0f, sl, out);
     else eu_synopsis<NCH, DEG, PLUS, GEN>(p, px, live, false, 0.0f, 0.0f, sl, out);
   } else {
 #pragma unroll
@@ -427,6 +513,7 @@ __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const
       const float cx = p.taps[3 * k], cy = p.taps[3 * k + 1], cw = p.taps[3 * k + 2];
       float help[NCH];
       if constexpr (HDR) eu_synopsis_hdr<NCH, DEG, GEN>(p, px, live, true, cx, cy, help);
+      else if constexpr (BIG) eu_synopsis_big<NCH, DEG, GEN>(p, px, live, true, cx, cy, sl, help);
       else eu_synopsis<NCH, DEG, PLUS, GEN>(p, px, live, true, cx, cy, sl, help);
 #pragma unroll
       for (int c = 0; c < NCH; c++) out[c] = out[c] + cw * help[c];
@@ -442,6 +529,13 @@ static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
   dim3 grid((unsigned)eu_xcd_grid(p.tiles_x, p.tiles_y, EU_UNIT_ROWS)), block(256);
   // alpha compositing keeps z (and, for up to EU_MULTI_KEEP facets, the source
   // coordinate) of every facet per thread in LDS
+  if (PLUS && !p.hdr && p.nfct > EU_MULTI_MAXF) {
+    if constexpr (PLUS) {
+      eu_multi_params q = p;           // the one instantiation serves jobs with and without generic-stepper facets
+      hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, true, false, true, true>), grid, block, 0, st, q);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   const size_t lds = PLUS && !p.hdr ? (size_t)(p.nfct <= EU_MULTI_KEEP ? 3 : 1) * p.nfct * 256 * sizeof(float) : 0;
   if (p.gen) {
     if (p.hdr) hipLaunchKernelGGL((eu_render_multi_kernel<NCH, -1, PLUS, true, true>), grid, block, lds, st, p);
@@ -491,8 +585,7 @@ extern "C" int eu_launch_render_multi_nch4(const eu_multi_params *p, int degree,
 extern "C" int eu_launch_render_multi(const void *pp, int degree, void *stream)
 {
   eu_multi_params p = *(const eu_multi_params *)pp;
-  // voronoi_syn and hdr_merge keep no per-facet state: any number of facets
-  if (p.nfct > EU_MULTI_MAXF && p.plus && !p.hdr) return -3;
+  // voronoi_syn and hdr_merge keep no per-facet state; alpha compositing beyond 64 facets: eu_synopsis_big
   p.tiles_x = (p.width + EU_TILE_W - 1) / EU_TILE_W;
   p.tiles_y = (p.row_end - p.row_begin + EU_TILE_H - 1) / EU_TILE_H;
   if (p.tiles_x <= 0 || p.tiles_y <= 0) return 0;
