@@ -226,6 +226,82 @@ EU_HD float eu_sincosf_impl(float y, int which)
   return eu_cos_poly(x2, neg);
 }
 
+/* glibc 2.35 tanf (sysdeps/ieee754/flt-32/s_tanf.c, k_tanf.c, e_rem_pio2f.c: fdlibm's float code, no FMA
+ * variant) for the arguments ba6_to_ray_t produces (geometry.h:855-1000: in-face coordinate * pi/4): no
+ * reduction up to pi/4, the n = +-1 special case of rem_pio2f up to 3 pi/4. Host check against the live
+ * libm, every float: identical for |x| <= 1.375 (in-face coordinates up to 1.75); in (1.387, 2.356) 963 of
+ * 2.1e8 arguments differ by one ulp (most of them next to pi/2), beyond 3 pi/4 it returns NaN. */
+EU_HD float eu_ktanf(float x, float y, int iy)
+{
+  const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f,
+              T4 = 8.8632395491e-03f, T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f,
+              T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f, T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f,
+              T12 = 2.5907305826e-05f;
+  const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+  float z, r, v, w, s;
+  const int32_t hx = (int32_t)eu_f2u(x);
+  const int32_t ix = hx & 0x7fffffff;
+  if (ix < 0x31800000) {
+    if ((int)x == 0) {
+      if ((ix | (iy + 1)) == 0) return 1.0f / eu_u2f((uint32_t)ix);
+      else if (iy == 1) return x;
+      else return -1.0f / x;
+    }
+  }
+  if (ix >= 0x3f2ca140) {
+    if (hx < 0) { x = -x; y = -y; }
+    z = pio4 - x;
+    w = pio4lo - y;
+    x = z + w; y = 0.0f;
+    if (eu_u2f(eu_f2u(x) & 0x7fffffffu) < 0x1p-13f) return (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x);
+  }
+  z = x * x;
+  w = z * z;
+  r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+  v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+  s = z * x;
+  r = y + z * (s * (r + v) + y);
+  r = r + T0 * s;
+  w = x + r;
+  if (ix >= 0x3f2ca140) {
+    v = (float)iy;
+    return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+  }
+  if (iy == 1) return w;
+  {
+    float a, t;
+    z = eu_u2f(eu_f2u(w) & 0xfffff000u);
+    v = r - (z - x);
+    t = a = -1.0f / w;
+    t = eu_u2f(eu_f2u(t) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+  }
+}
+
+EU_HD float eu_tanf(float x)
+{
+  const float pio2_1 = 1.5707855225e+00f, pio2_1t = 1.0804334124e-05f, pio2_2 = 1.0804273188e-05f,
+              pio2_2t = 6.0770999344e-11f;
+  const int32_t hx = (int32_t)eu_f2u(x), ix = hx & 0x7fffffff;
+  float y0, y1, z;
+  if (ix <= 0x3f490fda) return eu_ktanf(x, 0.0f, 1);
+  if (ix >= 0x7f800000) return x - x;
+  if (ix < 0x4016cbe4) {
+    if (hx > 0) {
+      z = x - pio2_1;
+      if ((ix & 0xfffffff0) != 0x3fc90fd0) { y0 = z - pio2_1t; y1 = (z - y0) - pio2_1t; }
+      else { z = z - pio2_2; y0 = z - pio2_2t; y1 = (z - y0) - pio2_2t; }
+    } else {
+      z = x + pio2_1;
+      if ((ix & 0xfffffff0) != 0x3fc90fd0) { y0 = z + pio2_1t; y1 = (z - y0) + pio2_1t; }
+      else { z = z + pio2_2; y0 = z + pio2_2t; y1 = (z - y0) + pio2_2t; }
+    }
+    return eu_ktanf(y0, y1, -1);
+  }
+  return eu_u2f(0x7fc00000u);
+}
+
 EU_HD float eu_sinf(float y) { return eu_sincosf_impl(y, 0); }
 EU_HD float eu_cosf(float y) { return eu_sincosf_impl(y, 1); }
 #endif

@@ -530,7 +530,7 @@ __device__ __forceinline__ void eu_rotate3(const float *m, float x, float y, flo
 
 // generic_stepper's tf (tf_ex_facet::eval, envutil_payload.cc:1869-1884): planar -> ray by the target's
 // projection (geometry.h: ll_to_ray_t :152-211, cyl_to_ray_t :417-446, rect_to_ray_t :363-387,
-// ster_to_ray_t :481-510, fish_to_ray_t :539-566, ir_to_ray_t :663-770), then tf3d_t::eval (:1896-1941; its all_of / any_of
+// ster_to_ray_t :481-510, fish_to_ray_t :539-566, ir_to_ray_t :663-770, ba6_to_ray_t :855-1000), then tf3d_t::eval (:1896-1941; its all_of / any_of
 // tests only skip work)
 __device__ __forceinline__ void eu_tf3d_eval(const eu_tf3d &g, float x, float y, float z, float &rx,
                                              float &ry, float &rz)
@@ -595,12 +595,17 @@ __device__ __forceinline__ void eu_generic_ray(const eu_generic &g, const eu_inv
     z = eu_cosf(p0); x = eu_sinf(p0); y = p1;
   } else if (g.prj == EU_RECTILINEAR) {
     x = p0; y = p1; z = 1.0f;
-  } else if (g.prj == EU_CUBEMAP) {
-    // ir_to_ray_t (geometry.h:663-770) as roll_out_23 default-constructs it: section_md 2, refc_md 1
+  } else if (g.prj == EU_CUBEMAP || g.prj == EU_BIATAN6) {
+    // ir_to_ray_t (geometry.h:663-770) / ba6_to_ray_t (:855-1000) as roll_out_23 default-constructs them:
+    // section_md 2, refc_md 1
     float c0 = p0 + 1.0f, c1 = p1 + 6.0f;
     const int section = (int)((double)c1 / 2.0);
     c1 = (float)((double)c1 - (double)section * 2.0);
     c0 = c0 - 1.0f; c1 = c1 - 1.0f;
+    if (g.prj == EU_BIATAN6) {
+      const float q = (float)(3.14159265358979323846 / 4);
+      c0 = eu_tanf(c0 * q); c1 = eu_tanf(c1 * q);
+    }
     x = 0.0f; y = 0.0f; z = 0.0f;
     if (section == 1)      { x = 1.0f;  y = c1;    z = -c0; }
     else if (section == 0) { x = -1.0f; y = c1;    z = c0; }

@@ -540,8 +540,8 @@ inline bool make_generic(const eu_target &t, const eu_facet &f, eu_generic &g)
   std::memset(&g, 0, sizeof g);
   switch (t.projection) {
     case EU_SPHERICAL: case EU_CYLINDRICAL: case EU_RECTILINEAR: case EU_STEREOGRAPHIC: case EU_FISHEYE:
-    case EU_CUBEMAP: break;
-    default: return false;       // biatan6: ba6_to_ray_t needs a per-pixel tanf that is not built
+    case EU_CUBEMAP: case EU_BIATAN6: break;
+    default: return false;
   }
   double ft6[6] = { 0, 0, 0, 0, 0, 0 };
   if (t.single) { ft6[0] = t.single->tr_x; ft6[1] = t.single->tr_y; ft6[2] = t.single->tr_z;

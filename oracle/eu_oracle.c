@@ -1261,12 +1261,16 @@ static int planar_to_ray_f(int projection, const float *in, float *out)
       out[2] = cosf(r); out[1] = -sinf(r) * cosf(phi); out[0] = sinf(r) * sinf(phi);
       return 1;
     }
-    case EUO_CUBEMAP: {          /* ir_to_ray_t, geometry.h:663-770, default-constructed by roll_out_23:
-                                  * section_md 2.0, refc_md 1.0 (a cubemap of 90-degree faces) */
+    case EUO_CUBEMAP:
+    case EUO_BIATAN6: {          /* ir_to_ray_t (geometry.h:663-770) / ba6_to_ray_t (:855-1000), default-constructed
+                                  * by roll_out_23: section_md 2.0, refc_md 1.0 (a cubemap of 90-degree faces) */
       float c0 = in[0] + 1.0f, c1 = in[1] + 6.0f;          /* crd2 += ul2c = { refc_md, 3 * section_md } */
       int section = (int)((double)c1 / 2.0);
       c1 = (float)((double)c1 - (double)section * 2.0);
       c0 -= 1.0f; c1 -= 1.0f;                              /* crd2 -= refc_md */
+      if (projection == EUO_BIATAN6) {                     /* crd2 = tan(crd2 * T(M_PI / 4)) */
+        c0 = tanf(c0 * (float)(M_PI / 4)); c1 = tanf(c1 * (float)(M_PI / 4));
+      }
       switch (section) {                                  /* CM_LEFT 0 .. CM_BACK 5, envutil_basic.h:56-64 */
         case 1: out[0] = 1.0f;  out[1] = c1;    out[2] = -c0; break;
         case 0: out[0] = -1.0f; out[1] = c1;    out[2] = c0;  break;
@@ -1279,7 +1283,7 @@ static int planar_to_ray_f(int projection, const float *in, float *out)
       return 1;
     }
   }
-  return 0;                      /* ba6_to_ray_t (needs a per-pixel tanf): not restated */
+  return 0;
 }
 
 /* tf3d_t::eval, geometry.h:1896-1941; the all_of / any_of tests only skip work */

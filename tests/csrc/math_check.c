@@ -127,3 +127,24 @@ long check_ster_angle_range(uint32_t first, uint32_t last, uint32_t *first_bad)
   if (first_bad) *first_bad = fb;
   return bad;
 }
+
+/* eu_tanf against libm's tanf for every float with |x| <= the float whose bits are `last` (both signs) */
+long check_tanf_range(uint32_t last, uint32_t *first_bad)
+{
+  long bad = 0;
+  uint32_t fb = 0;
+#pragma omp parallel for reduction(+:bad) schedule(static)
+  for (long long u = 0; u <= (long long)last; u++)
+    for (int sg = 0; sg < 2; sg++) {
+      float x;
+      uint32_t uu = (uint32_t)u | (sg ? 0x80000000u : 0u);
+      memcpy(&x, &uu, 4);
+      if (!same(eu_tanf(x), tanf(x))) {
+        bad++;
+#pragma omp critical
+        if (!fb) fb = uu;
+      }
+    }
+  if (first_bad) *first_bad = fb;
+  return bad;
+}

@@ -72,3 +72,12 @@ def test_stereographic_angle_all_floats(L):
     L.check_ster_angle_range.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
     first_bad = C.c_uint32(0)
     assert L.check_ster_angle_range(0, 0x7F800000, C.byref(first_bad)) == 0, hex(first_bad.value)
+
+
+def test_tanf_over_the_biatan6_domain(L):
+    """glibc 2.35 tanf restated for ba6_to_ray_t's arguments (in-face coordinate * pi/4): every float with
+    |x| <= 1.375, i.e. in-face coordinates up to 1.75 - the face ends at 1"""
+    L.check_tanf_range.restype = C.c_long
+    L.check_tanf_range.argtypes = [C.c_uint32, C.c_void_p]
+    first_bad = C.c_uint32(0)
+    assert L.check_tanf_range(0x3FB00000, C.byref(first_bad)) == 0, hex(first_bad.value)

@@ -15,7 +15,7 @@ import jobs
 pytestmark = pytest.mark.gpu
 
 FACET_PRJ = [euo.SPHERICAL, euo.CYLINDRICAL, euo.RECTILINEAR, euo.STEREOGRAPHIC, euo.FISHEYE]
-GENERIC_TRG = [ea.SPHERICAL, ea.CYLINDRICAL, ea.RECTILINEAR, ea.STEREOGRAPHIC, ea.FISHEYE, ea.CUBEMAP]
+GENERIC_TRG = [ea.SPHERICAL, ea.CYLINDRICAL, ea.RECTILINEAR, ea.STEREOGRAPHIC, ea.FISHEYE, ea.CUBEMAP, ea.BIATAN6]
 _s = os.environ.get("EU_FUZZ2_SEEDS")
 SEEDS = range(*[int(v) for v in _s.split(":")]) if _s else range(6)
 
@@ -99,7 +99,7 @@ def test_random_round2_jobs_bit_identical(seed):
             tdesc = f"single {sprj} {w}x{h} fov {hf:.1f} lens {lens} tr {tr}"
         else:
             tprj = GENERIC_TRG[rng.integers(len(GENERIC_TRG))]
-            if tprj == ea.CUBEMAP:
+            if tprj in (ea.CUBEMAP, ea.BIATAN6):
                 tw = int(rng.integers(8, 40)); th, thf = 6 * tw, 90.0
             else:
                 tw, th = int(rng.integers(8, 180)), int(rng.integers(8, 90))

@@ -12,7 +12,8 @@ import euo
 import jobs
 
 TARGETS = [(ea.SPHERICAL, 200, 100, 360.0), (ea.CYLINDRICAL, 180, 90, 200.0), (ea.RECTILINEAR, 150, 100, 80.0),
-           (ea.STEREOGRAPHIC, 120, 120, 200.0), (ea.FISHEYE, 120, 120, 170.0), (ea.CUBEMAP, 48, 288, 90.0)]
+           (ea.STEREOGRAPHIC, 120, 120, 200.0), (ea.FISHEYE, 120, 120, 170.0), (ea.CUBEMAP, 48, 288, 90.0),
+           (ea.BIATAN6, 40, 240, 90.0)]
 TR = dict(x=0.12, y=-0.07, z=0.05, tp_y=4.0, tp_p=-3.0, tp_r=1.5)
 
 
@@ -107,14 +108,6 @@ def test_mosaic_of_translated_and_plain_facets_bit_exact(nch, synopsis):
         for twine in (0, 2):
             a = ea.arguments(tprj, tw, th, hf, yaw=5, spline_degree=1, twine=twine, synopsis=synopsis)
             assert_bits(ea.render(a, gs, nch), jobs.oracle_render(a, os_), f"mosaic target {tprj} twine {twine} {synopsis}")
-
-
-@pytest.mark.gpu
-def test_translated_facet_on_a_biatan6_target_is_refused():
-    o, g = facet(euo.RECTILINEAR, 64, 64, 70.0, 3, 1, dict(x=0.1), True)
-    a = ea.arguments(ea.BIATAN6, 32, 192, 90.0, spline_degree=1)
-    with pytest.raises(Exception):
-        ea.render(a, g, 3)
 
 
 # ---- --single: the target recreates a facet (inverse lens correction, inverse translation) -------------
