@@ -170,6 +170,31 @@ def make_spread(w, h=0, d=1.0, sigma=0.0, threshold=0.0):
     return out[:k].copy()
 
 
+class MaskPolygon(C.Structure):
+    _fields_ = [("n", C.c_int), ("x", C.c_void_p), ("y", C.c_void_p)]
+
+
+def facet_alpha(pixels, polygons=(), crop=None, crop_kind=0):
+    """eu_hip_facet_alpha: PTO exclude masks (list of (xs, ys) vertex arrays) and the lens crop
+    (x0, x1, y0, y1; kind 1 rectangular, 2 elliptic) of a facet, multiplied into `pixels`
+    ((h, w, 2|4) float32, in place). Host function: works without a device. Returns the alpha plane."""
+    assert pixels.dtype == np.float32 and pixels.ndim == 3 and pixels.flags.c_contiguous
+    h, w, nch = pixels.shape
+    keep = [(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32)) for x, y in polygons]
+    arr = (MaskPolygon * max(len(keep), 1))()
+    for i, (x, y) in enumerate(keep):
+        arr[i].n, arr[i].x, arr[i].y = len(x), x.ctypes.data, y.ctypes.data
+    alpha = np.zeros((h, w), np.float32)
+    c = crop if crop is not None else (0, 0, 0, 0)
+    f = lib().eu_hip_facet_alpha
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    _check(f(_ptr(pixels), w, h, nch, C.cast(arr, C.c_void_p), len(keep), crop_kind if crop is not None else 0,
+             c[0], c[1], c[2], c[3], _ptr(alpha)))
+    return alpha
+
+
 def cubemap_metrics(face_px, face_fov=math.pi / 2, support_min=8, tile_px=64):
     sec, lf = C.c_int64(), C.c_int64()
     refc, m2p = C.c_double(), C.c_double()

@@ -12,6 +12,7 @@
 #include <new>
 #include "eu_device.h"
 #include "eu_setup_math.h"
+#include "eu_imageprep.h"
 #include "eu_math2.h"
 
 extern "C" int eu_launch_render(const eu_render_params *p, void *stream);
@@ -778,6 +779,30 @@ int eu_hip_make_spread(int w, int h, float d, float sigma, float threshold, floa
   if (n > max_taps) return fail(EU_ERR_ARGUMENT, "tap buffer too small");
   memcpy(taps, v.data(), v.size() * sizeof(float));
   return n;
+}
+
+int eu_hip_facet_alpha(float *pixels, int width, int height, int nchannels, const eu_mask_polygon *polygons,
+                       int npolygons, int crop_kind, int crop_x0, int crop_x1, int crop_y0, int crop_y1,
+                       float *alpha_out)
+{
+  if (width <= 0 || height <= 0 || (nchannels != 2 && nchannels != 4) || (!pixels && !alpha_out))
+    return fail(EU_ERR_ARGUMENT, "facet_alpha: width x height x {2, 4} channels");
+  if (npolygons < 0 || (npolygons > 0 && !polygons) || crop_kind < 0 || crop_kind > 2)
+    return fail(EU_ERR_ARGUMENT, "facet_alpha: polygons / crop kind");
+  std::vector<eu::mask_polygon> ps;
+  for (int i = 0; i < npolygons; i++) {
+    if (polygons[i].n < 0 || (polygons[i].n > 0 && (!polygons[i].x || !polygons[i].y)))
+      return fail(EU_ERR_ARGUMENT, "facet_alpha: polygon without vertices");
+    ps.push_back({ polygons[i].n, polygons[i].x, polygons[i].y });
+  }
+  std::vector<float> alpha;
+  try { alpha.resize(size_t(width) * height); } catch (...) { return fail(EU_ERR_MEMORY, "facet_alpha: host memory"); }
+  eu::facet_alpha(alpha.data(), width, height, ps.data(), int(ps.size()), crop_kind, crop_x0, crop_x1, crop_y0, crop_y1);
+  if (pixels)
+    for (size_t i = 0; i < alpha.size(); i++)
+      for (int c = 0; c < nchannels; c++) pixels[i * nchannels + c] = pixels[i * nchannels + c] * alpha[i];
+  if (alpha_out) memcpy(alpha_out, alpha.data(), alpha.size() * sizeof(float));
+  return EU_OK;
 }
 
 int eu_hip_cubemap_metrics(int face_px, double face_fov, int support_min, int tile_px,

@@ -63,6 +63,13 @@ struct facet_base : public extent_type
   }
 };
 
+// one PTO k-line (envutil_basic.h:387-411): variant 0 is an exclude mask of that image
+struct pto_mask_type
+{
+  int image = -1, variant = -1;
+  std::vector<float> vx, vy;
+};
+
 struct facet_spec : public facet_base
 {
   int facet_no = 0;
@@ -73,6 +80,10 @@ struct facet_spec : public facet_base
   int masked = -1;                // --mask_for (envutil_main.cc:1080-1092)
   bool has_lens_crop = false, has_pto_mask = false;
   int crop_x0 = 0, crop_x1 = 0, crop_y0 = 0, crop_y1 = 0;
+  std::vector<pto_mask_type> pto_mask_v;
+  // pixels_prepared: the caller has applied masks and crop to `pixels` (prepare_facet_pixels,
+  // eu_imageprep.hpp - what source_t's constructor does after read_image_data)
+  bool pixels_prepared = false;
   const float *pixels = nullptr;  // window_width x window_height x nchannels (cubemaps: 6 faces)
 };
 
@@ -184,14 +195,15 @@ struct hip_dispatch : public dispatch_base
     if (projection != args.projection) return EU_ERR_ARGUMENT;
     if ((ninputs == 9) != !args.twine_spread.empty()) return EU_ERR_ARGUMENT;
     if (args.tethered ? !args.p_screen_data : !args.p_output) return EU_ERR_ARGUMENT;
-    // outside this path: unstitching, masks, lens crops - the
-    // reference's CPU dispatch keeps them; an unknown synopsis is the reference's assert(false)
+    // outside this path: --mask_for (masking_t); PTO masks and lens crops edit the pixels at load
+    // time (prepare_facet_pixels) and must have been applied by the caller; an unknown synopsis is the reference's assert(false)
     // (envutil_payload.cc:2316-2318)
     if (args.synopsis != "panorama" && args.synopsis != "hdr_merge") return EU_ERR_ARGUMENT;
     // --split is the caller's loop over --single jobs (core(), envutil_main.cc:1676-1722)
     if (args.single >= int(args.facet_spec_v.size()) || args.solo >= int(args.facet_spec_v.size())) return EU_ERR_ARGUMENT;
     for (const auto &fct : args.facet_spec_v)
-      if (fct.has_pto_mask || fct.has_lens_crop || fct.masked != -1) return EU_ERR_UNSUPPORTED;
+      if (((fct.has_pto_mask || fct.has_lens_crop) && !fct.pixels_prepared &&
+           !resident.count(fct.asset_key)) || fct.masked != -1) return EU_ERR_UNSUPPORTED;
     std::vector<eu_source *> srcs;
     for (size_t fi = 0; fi < args.facet_spec_v.size(); fi++) {
       // --solo: only that facet takes part (fuse(), envutil_payload.cc:2085-2127)

@@ -346,6 +346,17 @@ inline bool init_arguments(int argc, const char *const *argv, const image_probe 
         if (fct.filename == fct.asset_key) suffix += a.pto_file + ".";
         fct.has_pto_mask = true;
         fct.asset_key += suffix + std::to_string(mask_no++);
+        // the polygon: pairs of numbers in the p field (envutil_main.cc:827-866)
+        pto_mask_type mask;
+        mask.image = image;
+        mask.variant = std::stoi(dir["t"]);
+        static const std::regex corner_re("([+-]?[0-9.]+)\\s([+-]?[0-9.]+)");
+        const std::string &vl = dir["p"];
+        for (auto ci = std::sregex_iterator(vl.begin(), vl.end(), corner_re); ci != std::sregex_iterator(); ++ci) {
+          mask.vx.push_back(float(std::stod((*ci)[1].str())));
+          mask.vy.push_back(float(std::stod((*ci)[2].str())));
+        }
+        fct.pto_mask_v.push_back(mask);
       }
     } catch (const std::exception &e) {
       err = std::string("malformed number in PTO script: ") + e.what();

@@ -172,6 +172,17 @@ double eu_hip_get_step(int projection, int width, int height, double hfov);
 int  eu_hip_make_spread(int w, int h, float d, float sigma, float threshold,
                         float *taps, int max_taps);
 /* metrics_t, cubemap.h:233-400: section_px, left/right frame, refc_md, model_to_px */
+/* PTO exclude masks and lens crops: the edit of a facet's loaded pixels that source_t's
+ * constructor makes before it prefilters (environment.h:700-890; fill_polygon,
+ * envutil_basic.cc:236-320; zimt::convolve with the binomial 1 4 6 4 1 / 16, REFLECT).
+ * HOST function, no device needed: `pixels` (width x height x nchannels, nchannels 2 or 4,
+ * alpha last) is multiplied in place, every channel, by the softened alpha plane; `alpha_out`
+ * (width x height floats) receives that plane when it is not NULL.
+ * crop_kind: 0 none, 1 rectangular [x0, x1) x [y0, y1), 2 elliptic (fisheye images). */
+typedef struct eu_mask_polygon { int n; const float *x; const float *y; } eu_mask_polygon;
+int  eu_hip_facet_alpha(float *pixels, int width, int height, int nchannels,
+                        const eu_mask_polygon *polygons, int npolygons, int crop_kind,
+                        int crop_x0, int crop_x1, int crop_y0, int crop_y1, float *alpha_out);
 int  eu_hip_cubemap_metrics(int face_px, double face_fov, int support_min,
                             int tile_px, int64_t *section_px,
                             int64_t *left_frame_px, double *refc_md,

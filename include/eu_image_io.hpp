@@ -1,0 +1,273 @@
+// eu_image_io.hpp - image files for the stand-alone command line (tools/envutil_hip.cc).
+//
+// The reference reads and writes every format through OpenImageIO (read_image_data /
+// save_array, envutil_basic.h:710-986), which this image does not have. What the path needs
+// from a file is what those two functions hand over: interleaved float pixels, x fastest, the
+// file's own channel count - and nothing else (no colour conversion: the reference only converts
+// when the file's colour space differs from the working one, and none of the formats below
+// carries one). Formats, chosen because they need no library and hold linear float or plain
+// integer samples:
+//   .pfm            Portable Float Map: "Pf" 1 channel, "PF" 3 channels, "PF4" 4 channels (the
+//                   extension several tools use for RGBA); float32, either byte order, rows
+//                   bottom to top
+//   .pgm .ppm .pnm  binary PNM (P5 / P6), 8 or 16 bit: value / maxval
+//   .pam            P7 (GRAYSCALE, GRAYSCALE_ALPHA, RGB, RGB_ALPHA), 8 or 16 bit: the integer
+//                   format with an alpha channel
+// Writing integer formats follows OpenImageIO's float -> unsigned conversion: clamp to [0, 1],
+// scale by maxval, add 0.5, truncate. Cubemaps: one image of aspect 1:6, or six files named by a
+// format string with one %s, filled with left, right, top, bottom, front, back (cubeface_series,
+// envutil_basic.h:267-340).
+//
+// Header-only, host code, no dependency on the HIP library.
+#ifndef EU_IMAGE_IO_HPP
+#define EU_IMAGE_IO_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace project {
+namespace io {
+
+struct header
+{
+  int width = 0, height = 0, nchannels = 0;
+  int maxval = 0;          // 0: float samples
+  bool little_endian = true;   // PFM
+  bool bottom_up = false;
+  long data_offset = 0;
+};
+
+inline std::string lower_ext(const std::string &name)
+{
+  const size_t dot = name.find_last_of('.');
+  if (dot == std::string::npos) return std::string();
+  std::string e = name.substr(dot + 1);
+  for (auto &c : e) c = char(c >= 'A' && c <= 'Z' ? c - 'A' + 'a' : c);
+  return e;
+}
+
+// next whitespace-separated token of a PNM header; '#' starts a comment up to the line's end
+inline bool token(FILE *f, std::string &t)
+{
+  t.clear();
+  int c;
+  for (;;) {
+    c = std::fgetc(f);
+    if (c == EOF) return false;
+    if (c == '#') { while ((c = std::fgetc(f)) != EOF && c != '\n') {} continue; }
+    if (c != ' ' && c != '\t' && c != '\n' && c != '\r') break;
+  }
+  while (c != EOF && c != ' ' && c != '\t' && c != '\n' && c != '\r') { t += char(c); c = std::fgetc(f); }
+  return true;   // exactly one whitespace character behind the token has been consumed
+}
+
+inline bool read_header(FILE *f, header &h, std::string &err)
+{
+  std::string magic, t;
+  if (!token(f, magic)) { err = "empty file"; return false; }
+  try {
+    if (magic == "PF" || magic == "Pf" || magic == "PF4") {
+      h.nchannels = magic == "Pf" ? 1 : magic == "PF" ? 3 : 4;
+      if (!token(f, t)) { err = "truncated header"; return false; }
+      h.width = std::stoi(t);
+      if (!token(f, t)) { err = "truncated header"; return false; }
+      h.height = std::stoi(t);
+      if (!token(f, t)) { err = "truncated header"; return false; }
+      h.little_endian = std::stod(t) < 0.0;
+      h.maxval = 0;
+      h.bottom_up = true;
+    } else if (magic == "P5" || magic == "P6") {
+      h.nchannels = magic == "P5" ? 1 : 3;
+      if (!token(f, t)) { err = "truncated header"; return false; }
+      h.width = std::stoi(t);
+      if (!token(f, t)) { err = "truncated header"; return false; }
+      h.height = std::stoi(t);
+      if (!token(f, t)) { err = "truncated header"; return false; }
+      h.maxval = std::stoi(t);
+    } else if (magic == "P7") {
+      for (;;) {
+        if (!token(f, t)) { err = "truncated header"; return false; }
+        if (t == "ENDHDR") break;
+        std::string v;
+        if (!token(f, v)) { err = "truncated header"; return false; }
+        if (t == "WIDTH") h.width = std::stoi(v);
+        else if (t == "HEIGHT") h.height = std::stoi(v);
+        else if (t == "DEPTH") h.nchannels = std::stoi(v);
+        else if (t == "MAXVAL") h.maxval = std::stoi(v);
+      }
+    } else {
+      err = "not a PFM / PNM / PAM file (magic '" + magic + "')";
+      return false;
+    }
+  } catch (...) { err = "malformed header"; return false; }
+  if (h.width <= 0 || h.height <= 0 || h.nchannels < 1 || h.nchannels > 4 || h.maxval < 0 || h.maxval > 65535) {
+    err = "unsupported image geometry";
+    return false;
+  }
+  h.data_offset = std::ftell(f);
+  return true;
+}
+
+inline bool probe_one(const std::string &name, header &h, std::string &err)
+{
+  FILE *f = std::fopen(name.c_str(), "rb");
+  if (!f) { err = "cannot open " + name; return false; }
+  const bool ok = read_header(f, h, err);
+  std::fclose(f);
+  if (!ok) err = name + ": " + err;
+  return ok;
+}
+
+// cubeface_series (envutil_basic.h:267-340): six names from a format string with ONE percent sign
+inline bool cubeface_names(const std::string &fmt, std::vector<std::string> &names)
+{
+  size_t count = 0;
+  for (char c : fmt) count += c == '%';
+  const size_t p = fmt.find("%s");
+  if (count != 1 || p == std::string::npos) return false;
+  static const char *const face[6] = { "left", "right", "top", "bottom", "front", "back" };
+  names.clear();
+  for (int i = 0; i < 6; i++) names.push_back(fmt.substr(0, p) + face[i] + fmt.substr(p + 2));
+  return true;
+}
+
+// facet_base::get_image_metrics (envutil_basic.h:546-589): a name with a percent sign is a set
+// of six cube faces and reports the metrics of the first
+inline bool probe(const std::string &name, int &width, int &height, int &nchannels, std::string &err)
+{
+  header h;
+  std::vector<std::string> faces;
+  const bool series = name.find('%') != std::string::npos;
+  if (series && !cubeface_names(name, faces)) { err = "a format string needs exactly one %s: " + name; return false; }
+  if (!probe_one(series ? faces[0] : name, h, err)) return false;
+  width = h.width; height = h.height; nchannels = h.nchannels;
+  return true;
+}
+
+// rows top to bottom, interleaved, the file's own channel count
+inline bool read_one(const std::string &name, header &h, float *dst, std::string &err)
+{
+  FILE *f = std::fopen(name.c_str(), "rb");
+  if (!f) { err = "cannot open " + name; return false; }
+  header g;
+  if (!read_header(f, g, err)) { std::fclose(f); err = name + ": " + err; return false; }
+  if (h.width && (g.width != h.width || g.height != h.height || g.nchannels != h.nchannels)) {
+    std::fclose(f);
+    err = name + ": size differs from the first image of the set";
+    return false;
+  }
+  h = g;
+  const size_t row = size_t(h.width) * h.nchannels;
+  bool ok = true;
+  if (h.maxval == 0) {
+    const uint16_t one = 1;
+    const bool host_little = *reinterpret_cast<const uint8_t *>(&one) == 1;
+    for (int y = 0; y < h.height && ok; y++) {
+      float *d = dst + size_t(h.bottom_up ? h.height - 1 - y : y) * row;
+      ok = std::fread(d, 4, row, f) == row;
+      if (ok && host_little != h.little_endian)
+        for (size_t i = 0; i < row; i++) {
+          uint32_t u;
+          std::memcpy(&u, d + i, 4);
+          u = (u >> 24) | ((u >> 8) & 0xff00u) | ((u << 8) & 0xff0000u) | (u << 24);
+          std::memcpy(d + i, &u, 4);
+        }
+    }
+  } else {
+    const int bytes = h.maxval > 255 ? 2 : 1;
+    std::vector<uint8_t> buf(row * bytes);
+    const float mv = float(h.maxval);
+    for (int y = 0; y < h.height && ok; y++) {
+      ok = std::fread(buf.data(), 1, buf.size(), f) == buf.size();
+      float *d = dst + size_t(y) * row;
+      if (bytes == 1) for (size_t i = 0; i < row; i++) d[i] = float(buf[i]) / mv;
+      else for (size_t i = 0; i < row; i++) d[i] = float((unsigned(buf[2 * i]) << 8) | buf[2 * i + 1]) / mv;   // big endian
+    }
+  }
+  std::fclose(f);
+  if (!ok) err = name + ": truncated pixel data";
+  return ok;
+}
+
+// a facet's pixels: a single image, or six cube faces stacked to the 1:6 image
+inline bool read_image(const std::string &name, std::vector<float> &pixels, int &width, int &height,
+                       int &nchannels, std::string &err)
+{
+  std::vector<std::string> faces;
+  if (name.find('%') != std::string::npos) {
+    if (!cubeface_names(name, faces)) { err = "a format string needs exactly one %s: " + name; return false; }
+  } else faces.push_back(name);
+  header h;
+  if (!probe_one(faces[0], h, err)) return false;
+  const size_t per = size_t(h.width) * h.height * h.nchannels;
+  pixels.resize(per * faces.size());
+  for (size_t i = 0; i < faces.size(); i++)
+    if (!read_one(faces[i], h, pixels.data() + i * per, err)) return false;
+  width = h.width; height = h.height * int(faces.size()); nchannels = h.nchannels;
+  return true;
+}
+
+inline bool write_one(const std::string &name, const float *src, int width, int height, int nch, std::string &err)
+{
+  const std::string ext = lower_ext(name);
+  FILE *f = std::fopen(name.c_str(), "wb");
+  if (!f) { err = "cannot create " + name; return false; }
+  const size_t row = size_t(width) * nch;
+  bool ok = true;
+  if (ext == "pfm") {
+    if (nch == 2) { std::fclose(f); err = name + ": PFM holds 1, 3 or 4 channels; use .pam for 2"; return false; }
+    const uint16_t one = 1;
+    const bool host_little = *reinterpret_cast<const uint8_t *>(&one) == 1;
+    std::fprintf(f, "%s\n%d %d\n%s\n", nch == 1 ? "Pf" : nch == 3 ? "PF" : "PF4", width, height, host_little ? "-1.0" : "1.0");
+    for (int y = height - 1; y >= 0 && ok; y--) ok = std::fwrite(src + size_t(y) * row, 4, row, f) == row;
+  } else if (ext == "pgm" || ext == "ppm" || ext == "pnm" || ext == "pam") {
+    const bool pam = ext == "pam";
+    if (!pam && nch != 1 && nch != 3) { std::fclose(f); err = name + ": PNM holds 1 or 3 channels; use .pam or .pfm"; return false; }
+    const int maxval = pam ? 65535 : 255;
+    if (pam) {
+      static const char *const tt[5] = { "", "GRAYSCALE", "GRAYSCALE_ALPHA", "RGB", "RGB_ALPHA" };
+      std::fprintf(f, "P7\nWIDTH %d\nHEIGHT %d\nDEPTH %d\nMAXVAL %d\nTUPLTYPE %s\nENDHDR\n", width, height, nch, maxval, tt[nch]);
+    } else std::fprintf(f, "%s\n%d %d\n%d\n", nch == 1 ? "P5" : "P6", width, height, maxval);
+    std::vector<uint8_t> buf(row * (pam ? 2 : 1));
+    for (int y = 0; y < height && ok; y++) {
+      const float *s = src + size_t(y) * row;
+      for (size_t i = 0; i < row; i++) {
+        float v = s[i];
+        v = v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v;      // NaN fails both tests and is written as 0 below
+        const unsigned q = v == v ? unsigned(v * float(maxval) + 0.5f) : 0u;
+        if (pam) { buf[2 * i] = uint8_t(q >> 8); buf[2 * i + 1] = uint8_t(q & 255u); }
+        else buf[i] = uint8_t(q);
+      }
+      ok = std::fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    }
+  } else {
+    std::fclose(f);
+    err = name + ": output formats are .pfm, .pgm, .ppm, .pnm, .pam";
+    return false;
+  }
+  ok = std::fclose(f) == 0 && ok;
+  if (!ok) err = name + ": write failed";
+  return ok;
+}
+
+// save_array (envutil_basic.h:710-815): a cubemap target whose output name is a format string
+// goes to six face images, everything else to one file
+inline bool write_image(const std::string &name, const float *src, int width, int height, int nch,
+                        bool cubemap, std::string &err)
+{
+  std::vector<std::string> faces;
+  if (cubemap && name.find('%') != std::string::npos && cubeface_names(name, faces)) {
+    if (height != 6 * width) { err = "a cubemap is 1:6"; return false; }
+    for (int i = 0; i < 6; i++)
+      if (!write_one(faces[size_t(i)], src + size_t(i) * width * width * nch, width, width, nch, err)) return false;
+    return true;
+  }
+  return write_one(name, src, width, height, nch, err);
+}
+
+}  // namespace io
+}  // namespace project
+#endif

@@ -2287,3 +2287,136 @@ void euo_ray_to_prj_d(int projection, const double *in, double *out)
     }
   }
 }
+
+
+/* ---------------------------------------------------------------------------
+ * PTO exclude masks and lens crops: the alpha plane of a facet
+ * (environment.h:727-843). Restated loop for loop.
+ * ------------------------------------------------------------------------- */
+
+/* zimt/extrapolate.h:141-155 */
+static float fir_reflect(const float *buf, long stride, int n, int i)
+{
+  if (i < 0) i = -1 - i;
+  if (i >= n) {
+    i %= 2 * n;
+    if (i >= n) i = 2 * n - 1 - i;
+  }
+  return buf[(long)i * stride];
+}
+
+/* fir_filter::solve, zimt/convolve.h:240-383, for the 5-tap kernel with headroom 2: a
+ * circular buffer of the last five samples, the kernel stored twice so that a pointer into
+ * it lines the weights up with the slots; the slots are summed in slot order. `in` is a
+ * private copy of the line (the filter driver buffers lines), `out` strided. */
+static void fir_line(const float *in, int n, float *out, long ostride)
+{
+  enum { K = 5, HEAD = 2 };
+  const double kd[K] = { 1.0 / 16.0, 4.0 / 16.0, 6.0 / 16.0, 4.0 / 16.0, 1.0 / 16.0 };
+  float circ[K], kern[2 * K], tail[K];
+  for (int i = 0; i < K; i++) kern[i] = kern[i + K] = (float)(long double)kd[i];
+  int si = -HEAD, ti = 0;
+  for (int i = 0; i < K; i++, si++) circ[i] = fir_reflect(in, 1, n, si);
+  for (int i = 0, z = n; i < K - HEAD; i++, z++) tail[i] = fir_reflect(in, 1, n, z);
+  while (ti < n) {
+    const float *pk = kern + K;
+    float *pd = circ;
+    for (int i = 0; i < K && ti < n; i++) {
+      float result = circ[0] * pk[0];
+      for (int j = 1; j < K; j++) result += circ[j] * pk[j];
+      out[(long)ti * ostride] = result;
+      *pd = si < n ? in[si] : tail[si - n];
+      ++si; ++ti; ++pd; --pk;
+    }
+  }
+}
+
+void euo_binomial_plane(float *plane, int w, int h)
+{
+  int m = w > h ? w : h;
+  float *line = (float *)malloc((size_t)m * sizeof(float));
+  for (int y = 0; y < h; y++) {                 /* axis 0 */
+    memcpy(line, plane + (long)y * w, (size_t)w * sizeof(float));
+    fir_line(line, w, plane + (long)y * w, 1);
+  }
+  for (int x = 0; x < w; x++) {                 /* axis 1 */
+    for (int y = 0; y < h; y++) line[y] = plane[(long)y * w + x];
+    fir_line(line, h, plane + x, w);
+  }
+  free(line);
+}
+
+/* fill_polygon, envutil_basic.cc:236-320 */
+static void fill_polygon_clear(float *alpha, int w, const float *px, const float *py, int N,
+                               int LEFT, int TOP, int RIGHT, int BOT)
+{
+  int *nodeX = (int *)malloc((size_t)(N + 1) * sizeof(int)), *dir = (int *)malloc((size_t)(N + 1) * sizeof(int));
+  for (int pixelY = TOP; pixelY < BOT; pixelY++) {
+    int nodes = 0, j = N - 1, i, swap;
+    for (i = 0; i < N; i++) {
+      int cross = 0;
+      if (py[i] < (float)pixelY && py[j] >= (float)pixelY) cross = 1;
+      else if (py[j] < (float)pixelY && py[i] >= (float)pixelY) cross = -1;
+      if (cross) {
+        nodeX[nodes] = (int)(px[i] + (pixelY - py[i]) / (py[j] - py[i]) * (px[j] - px[i]));
+        dir[nodes++] = cross;
+      }
+      j = i;
+    }
+    i = 0;
+    while (i < nodes - 1) {
+      if (nodeX[i] > nodeX[i + 1]) {
+        swap = nodeX[i]; nodeX[i] = nodeX[i + 1]; nodeX[i + 1] = swap;
+        swap = dir[i]; dir[i] = dir[i + 1]; dir[i + 1] = swap;
+        if (i) i--;
+      } else i++;
+    }
+    int w_ord = 0;
+    for (i = 0; i < nodes; i++) {
+      w_ord += dir[i];
+      if (!w_ord) continue;
+      if (i + 1 >= nodes) break;
+      if (nodeX[i] >= RIGHT) break;
+      if (nodeX[i + 1] > LEFT) {
+        if (nodeX[i] < LEFT) nodeX[i] = LEFT;
+        if (nodeX[i + 1] > RIGHT) nodeX[i + 1] = RIGHT;
+        for (int pixelX = nodeX[i]; pixelX < nodeX[i + 1]; pixelX++) alpha[(long)pixelY * w + pixelX] = 0.0f;
+      }
+    }
+  }
+  free(nodeX); free(dir);
+}
+
+void euo_facet_alpha(float *alpha, int w, int h, int npolys, const int *counts, const float *xs,
+                     const float *ys, int crop_kind, int cx0, int cx1, int cy0, int cy1, int stage)
+{
+  for (long i = 0; i < (long)w * h; i++) alpha[i] = 1.0f;
+  long off = 0;
+  for (int p = 0; p < npolys; p++) {
+    fill_polygon_clear(alpha, w, xs + off, ys + off, counts[p], 0, 0, w, h);
+    off += counts[p];
+  }
+  if (crop_kind == 2) {
+    float a = (float)(fabs((double)(cx1 - cx0)) / 2.0);
+    float b = (float)(fabs((double)(cy1 - cy0)) / 2.0);
+    float mx = (float)((cx0 + cx1) / 2.0);
+    float my = (float)((cy0 + cy1) / 2.0);
+    for (int y = 0; y < h; y++) {
+      float dy = fabsf(y - my);
+      if (dy > b) {
+        for (int x = 0; x < w; x++) alpha[(long)y * w + x] = 0;
+        continue;
+      }
+      float xmargin = (float)sqrt((a * a) * (1.0 - (dy * dy) / (b * b)));
+      for (int x = 0; x < w; x++) {
+        float dx = fabsf(x - mx);
+        if (dx > xmargin) alpha[(long)y * w + x] = 0;
+      }
+    }
+  } else if (crop_kind == 1) {
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++)
+        if (x < cx0 || x >= cx1 || y < cy0 || y >= cy1) alpha[(long)y * w + x] = 0;
+  }
+  if (stage >= 1) euo_binomial_plane(alpha, w, h);
+}

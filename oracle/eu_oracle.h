@@ -163,6 +163,15 @@ void   euo_lens_factor(double a, double b, double c, const float *x, long n, flo
  * knots of the model (0: too many), knots = its prefiltered core */
 int    euo_inverse_lcp(double a, double b, double c, double r_max, int sz, const float *x, long n,
                        float *out, float *knots, int max_knots);
+/* a masked / cropped facet's alpha plane (environment.h:727-843): 1 everywhere, PTO exclude
+ * polygons (fill_polygon, envutil_basic.cc:236-320) and the outside of the lens crop cleared,
+ * then zimt::convolve with the binomial 1 4 6 4 1 / 16, REFLECT, along both axes.
+ * polygons: counts[npolys] vertices each, coordinates concatenated in xs / ys.
+ * crop_kind 0 none, 1 rectangular, 2 elliptic. stage 0: before the convolution, 1: after. */
+void   euo_facet_alpha(float *alpha, int w, int h, int npolys, const int *counts, const float *xs,
+                       const float *ys, int crop_kind, int cx0, int cx1, int cy0, int cy1, int stage);
+/* the binomial alone, in place (pinned against zimt::convolve through oracle/_ref) */
+void   euo_binomial_plane(float *plane, int w, int h);
 void   euo_source_coordinates(const euo_source *src, const float *rays, long n, float *out3);
 void   euo_prj_to_ray_d(int projection, const double *in2, double *out3);
 void   euo_ray_to_prj_d(int projection, const double *in3, double *out2);

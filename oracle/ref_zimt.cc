@@ -13,6 +13,8 @@
 // segment 512, compiled with -ffp-contract=off: the pinned oracle definition
 // of SURVEY.md §8(c).
 //
+//   * the binomial that softens a masked facet's alpha plane (zimt/convolve.h, called with the
+//     arguments of environment.h:833-843)
 //   * the PTO lens polynomial lcp            (lens_correction.h: it includes nothing
 //     but zimt/eval.h, so it compiles in place)
 // envutil's other headers (geometry.h, stepper.h, environment.h, cubemap.h,
@@ -28,6 +30,7 @@
 #include "zimt/bspline.h"
 #include "zimt/prefilter.h"
 #include "zimt/eval.h"
+#include "zimt/convolve.h"
 #include "lens_correction.h"
 
 namespace {
@@ -296,4 +299,13 @@ extern "C" void ref_inverse_lcp(double a, double b, double c, double r_max, int 
     for (std::size_t l = 0; l < L && i0 + (long)l < n; l++) out[i0 + l] = r[l];
   }
   for (int i = 0; knots && i < f.nk && i < max_knots; i++) knots[i] = f.inv_model.core[i];
+}
+
+// zimt::convolve on a w x h float plane, in place, with the call of environment.h:833-843:
+// binomial 1 4 6 4 1 / 16, headroom 2, REFLECT on both axes, all axes
+extern "C" void ref_binomial_alpha(float *plane, long w, long h)
+{
+  zimt::view_t<2, float> alpha(plane, {1L, w}, {std::size_t(w), std::size_t(h)});
+  zimt::convolve(alpha, alpha, {zimt::REFLECT, zimt::REFLECT},
+                 {1.0 / 16.0, 4.0 / 16.0, 6.0 / 16.0, 4.0 / 16.0, 1.0 / 16.0}, 2);
 }

@@ -70,12 +70,21 @@ int main(int argc, char **argv)
                 "\"y1\": %.17g, \"step\": %.17g, \"brighten\": %.9g, \"a\": %.17g, \"b\": %.17g, \"c\": %.17g, "
                 "\"h\": %.17g, \"v\": %.17g, \"s\": %.17g, \"shear_g\": %.17g, \"shear_t\": %.17g, "
                 "\"has_lcp\": %d, \"has_shift\": %d, \"has_shear\": %d, \"tr\": [%.17g, %.17g, %.17g], "
-                "\"has_lens_crop\": %d, \"has_pto_mask\": %d, \"masked\": %d}",
+                "\"has_lens_crop\": %d, \"has_pto_mask\": %d, \"masked\": %d, \"lens_crop\": [%d, %d, %d, %d], "
+                "\"masks\": [",
                 i ? ",\n  " : "", esc(f.filename).c_str(), esc(f.asset_key).c_str(), int(f.projection), f.hfov, f.width,
                 f.height, f.window_width, f.window_height, f.window_x_offset, f.window_y_offset, f.nchannels,
                 f.yaw, f.pitch, f.roll, f.x0, f.x1, f.y0, f.y1, f.step, double(f.brighten), f.a, f.b, f.c, f.h,
                 f.v, f.s, f.shear_g, f.shear_t, int(f.has_lcp), int(f.has_shift), int(f.has_shear), f.tr_x,
-                f.tr_y, f.tr_z, int(f.has_lens_crop), int(f.has_pto_mask), f.masked);
+                f.tr_y, f.tr_z, int(f.has_lens_crop), int(f.has_pto_mask), f.masked, f.crop_x0, f.crop_x1, f.crop_y0,
+                f.crop_y1);
+    for (size_t m = 0; m < f.pto_mask_v.size(); m++) {
+      std::printf("%s{\"variant\": %d, \"xy\": [", m ? ", " : "", f.pto_mask_v[m].variant);
+      for (size_t v = 0; v < f.pto_mask_v[m].vx.size(); v++)
+        std::printf("%s%.9g, %.9g", v ? ", " : "", double(f.pto_mask_v[m].vx[v]), double(f.pto_mask_v[m].vy[v]));
+      std::printf("]}");
+    }
+    std::printf("]}");
   }
   std::printf("]}\n");
   if (std::getenv("EU_TEST_RENDER")) {

@@ -226,3 +226,29 @@ def source_coordinates(src, rays):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     f(C.byref(src), rays.ctypes.data, len(rays), out.ctypes.data)
     return out
+
+
+def facet_alpha(w, h, polygons=(), crop=None, crop_kind=0, stage=1):
+    """the oracle's alpha plane of a masked / cropped facet (oracle/eu_oracle.c: euo_facet_alpha);
+    stage 0 stops before the binomial"""
+    counts = np.array([len(x) for x, _ in polygons] or [0], np.int32)
+    xs = np.ascontiguousarray(np.concatenate([np.asarray(x, np.float32) for x, _ in polygons] or [np.zeros(1, np.float32)]))
+    ys = np.ascontiguousarray(np.concatenate([np.asarray(y, np.float32) for _, y in polygons] or [np.zeros(1, np.float32)]))
+    alpha = np.zeros((h, w), np.float32)
+    c = crop if crop is not None else (0, 0, 0, 0)
+    f = lib().euo_facet_alpha
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
+    f(alpha.ctypes.data, w, h, len(polygons), counts.ctypes.data, xs.ctypes.data, ys.ctypes.data,
+      crop_kind if crop is not None else 0, c[0], c[1], c[2], c[3], stage)
+    return alpha
+
+
+def binomial_plane(plane):
+    """zimt::convolve with 1 4 6 4 1 / 16, REFLECT, both axes, as the oracle restates it"""
+    out = np.ascontiguousarray(plane, np.float32).copy()
+    f = lib().euo_binomial_plane
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    f(out.ctypes.data, out.shape[1], out.shape[0])
+    return out

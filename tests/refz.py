@@ -146,3 +146,14 @@ def inverse_lcp(a, b, c, r_max, sz, x):
     f.argtypes = [C.c_double] * 4 + [C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int]
     f(a, b, c, r_max, sz, x.ctypes.data, len(x), out.ctypes.data, knots.ctypes.data, len(knots))
     return out, knots
+
+
+def binomial_alpha(plane):
+    """zimt::convolve(alpha, alpha, {REFLECT, REFLECT}, {1, 4, 6, 4, 1} / 16, 2): the call of
+    environment.h:833-843 on a (h, w) float plane"""
+    out = np.ascontiguousarray(plane, np.float32).copy()
+    f = lib().ref_binomial_alpha
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_long, C.c_long]
+    f(out.ctypes.data, out.shape[1], out.shape[0])
+    return out

@@ -1,0 +1,175 @@
+"""The stand-alone command line (tools/envutil_hip.cc -> envutil_amd/bin/envutil_hip): envutil's
+options and PTO handling (include/eu_frontend.hpp), PFM / PNM / PAM image files
+(include/eu_image_io.hpp), PTO masks and lens crops applied to the loaded pixels
+(include/eu_imageprep.hpp), payload() on the HIP library. CPU tests: the program builds, reports
+errors instead of asserting, and fails loudly without a device. GPU tests: the files it writes hold
+the same bits as the same jobs rendered through the Python binding."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import envutil_amd as ea
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "envutil_amd", "bin", "envutil_hip")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    if not os.path.exists(EXE) or not os.path.exists(ea.lib_path()):
+        ea.build()
+
+    def run(argv, cwd, stdin=None):
+        return subprocess.run([EXE] + list(argv), capture_output=True, text=True, cwd=str(cwd), input=stdin, timeout=600)
+    return run
+
+
+def write_pfm(path, img):
+    h, w = img.shape[:2]
+    n = 1 if img.ndim == 2 else img.shape[2]
+    magic = {1: b"Pf", 3: b"PF", 4: b"PF4"}[n]
+    with open(path, "wb") as f:
+        f.write(magic + b"\n%d %d\n-1.0\n" % (w, h))
+        f.write(np.ascontiguousarray(img[::-1], "<f4").tobytes())
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        magic = f.readline().strip()
+        w, h = map(int, f.readline().split())
+        scale = float(f.readline())
+        n = {b"Pf": 1, b"PF": 3, b"PF4": 4}[magic]
+        a = np.frombuffer(f.read(), "<f4" if scale < 0 else ">f4").reshape(h, w, n)
+    return np.ascontiguousarray(a[::-1]).astype(np.float32)
+
+
+def synth(w, h, n, seed=0):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([0.5 + 0.3 * np.sin(x / (5.0 + c)) * np.cos(y / (7.0 + c)) for c in range(n)], 2)
+    return (img + 0.05 * rng.random((h, w, n))).astype(np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+# ---------------------------------------------------------------------------------- CPU
+
+def test_errors_are_messages(cli, tmp_path):
+    write_pfm(tmp_path / "a.pfm", synth(32, 16, 3))
+    r = cli(["--facet", "nope.pfm", "spherical", "360", "0", "0", "0", "--output", "o.pfm"], tmp_path)
+    assert r.returncode == 2 and "failed to open facet image" in r.stderr
+    r = cli(["--facet", "a.pfm", "spherical", "360", "0", "0", "0", "--bogus", "1", "--output", "o.pfm"], tmp_path)
+    assert r.returncode == 2 and "unknown option" in r.stderr
+    (tmp_path / "junk.pfm").write_bytes(b"GIF89a....")
+    r = cli(["--facet", "junk.pfm", "spherical", "360", "0", "0", "0", "--output", "o.pfm"], tmp_path)
+    assert r.returncode == 2
+    assert cli([], tmp_path).returncode == 2
+
+
+def test_no_device_is_a_loud_failure(cli, tmp_path):
+    if ea.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    write_pfm(tmp_path / "a.pfm", synth(32, 16, 3))
+    r = cli(["--facet", "a.pfm", "spherical", "360", "0", "0", "0", "--projection", "cubemap", "--hfov", "90",
+             "--width", "8", "--output", "o.pfm"], tmp_path)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and not (tmp_path / "o.pfm").exists()
+
+
+# ---------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+def test_latlon_to_cubemap_files(cli, tmp_path):
+    img = synth(256, 128, 3)
+    write_pfm(tmp_path / "pano.pfm", img)
+    r = cli(["--facet", "pano.pfm", "spherical", "360", "0", "0", "0", "--projection", "cubemap", "--hfov", "90",
+             "--width", "64", "--degree", "3", "--twine", "0", "--output", "cube.pfm", "-v"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 256, 128, 360.0), img, 3)
+    want = ea.render(ea.arguments(ea.CUBEMAP, 64, 384, 90.0, spline_degree=3), src)
+    assert (bits(read_pfm(tmp_path / "cube.pfm")) == bits(want)).all()
+    # six face files by a format string, 16-bit PAM: the same pixels quantised as OpenImageIO does
+    r = cli(["--facet", "pano.pfm", "spherical", "360", "0", "0", "0", "--projection", "cubemap", "--hfov", "90",
+             "--width", "64", "--degree", "3", "--twine", "0", "--output", "face_%s.pam"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    for i, name in enumerate(["left", "right", "top", "bottom", "front", "back"]):
+        raw = (tmp_path / f"face_{name}.pam").read_bytes()
+        head, _, data = raw.partition(b"ENDHDR\n")
+        assert b"WIDTH 64" in head and b"DEPTH 3" in head and b"MAXVAL 65535" in head
+        q = np.frombuffer(data, ">u2").reshape(64, 64, 3)
+        face = np.clip(want[64 * i:64 * (i + 1)], 0, 1)
+        assert (q == (face * np.float32(65535) + np.float32(0.5)).astype(np.uint32)).all()
+    # ... and the six faces read back as a cubemap source
+    r = cli(["--facet", "face_%s.pam", "cubemap", "90", "0", "0", "0", "--projection", "spherical", "--hfov", "360",
+             "--width", "128", "--degree", "1", "--twine", "0", "--output", "back.pfm"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    faces = np.concatenate([np.frombuffer((tmp_path / f"face_{n}.pam").read_bytes().partition(b"ENDHDR\n")[2], ">u2")
+                            .reshape(64, 64, 3) for n in ["left", "right", "top", "bottom", "front", "back"]])
+    fimg = (faces.astype(np.float32) / np.float32(65535)).astype(np.float32)
+    csrc = ea.Source.load(ea.facet_spec(ea.CUBEMAP, 64, 384, 90.0), fimg, 1)
+    want2 = ea.render(ea.arguments(ea.SPHERICAL, 128, 64, 360.0, spline_degree=1), csrc)
+    assert (bits(read_pfm(tmp_path / "back.pfm")) == bits(want2)).all()
+
+
+@pytest.mark.gpu
+def test_pto_with_mask_and_crop(cli, tmp_path):
+    """a PTO with an exclude mask on one image and a lens crop on a fisheye image: both facets gain an
+    alpha channel, the masked regions are transparent in the output"""
+    a, b = synth(200, 150, 3, 1), synth(160, 160, 3, 2)
+    write_pfm(tmp_path / "a.pfm", a)
+    write_pfm(tmp_path / "b.pfm", b)
+    (tmp_path / "two.pto").write_text(
+        'p f2 w300 h150 v360 n"TIFF"\n'
+        'i w200 h150 f0 v70 y10 p5 r2 n"a.pfm"\n'
+        'i w160 h160 f3 v170 y-100 p-20 r0 S10,150,10,150 n"b.pfm"\n'
+        'k i0 t0 p"30 20 120 25 140 110 40 100"\n')
+    r = cli(["--pto", "two.pto", "--output", "o.pfm", "--degree", "1", "--twine", "0"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    out = read_pfm(tmp_path / "o.pfm")
+    assert out.shape == (150, 300, 4)
+    # the same job through the binding, the pixels prepared with the library's host function
+    pa = np.concatenate([a, np.ones((150, 200, 1), np.float32)], 2)
+    pb = np.concatenate([b, np.ones((160, 160, 1), np.float32)], 2)
+    ea.facet_alpha(pa, [(np.array([30, 120, 140, 40], np.float32), np.array([20, 25, 110, 100], np.float32))])
+    ea.facet_alpha(pb, crop=(10, 150, 10, 150), crop_kind=2)
+    fa = ea.facet_spec(ea.RECTILINEAR, 200, 150, 70.0, nchannels=4, yaw=10, pitch=5, roll=2)
+    fb = ea.facet_spec(ea.FISHEYE, 160, 160, 170.0, nchannels=4, yaw=-100, pitch=-20, roll=0)
+    sa, sb = ea.Source.load(fa, pa, 1), ea.Source.load(fb, pb, 1)
+    want = ea.render(ea.arguments(ea.SPHERICAL, 300, 150, 360.0, spline_degree=1), [sa, sb], 4)
+    assert (bits(out) == bits(want)).all()
+    assert (out[..., 3] == 0).any() and (out[..., 3] == 1).any()
+
+
+@pytest.mark.gpu
+def test_pipe_mode_keeps_assets_resident(cli, tmp_path):
+    img = synth(128, 64, 3, 5)
+    write_pfm(tmp_path / "pano.pfm", img)
+    jobs = "--yaw 0 --output v0.pfm\n--yaw 45 --output 'v 45.pfm'\n"
+    r = cli(["-v", "--facet", "pano.pfm", "spherical", "360", "0", "0", "0", "--projection", "rectilinear", "--hfov", "80",
+             "--width", "96", "--height", "64", "--degree", "2", "--twine", "0", "-"], tmp_path, stdin=jobs)
+    assert r.returncode == 0, r.stderr
+    assert "already resident" in r.stdout
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 128, 64, 360.0), img, 2)
+    for yaw, name in ((0, "v0.pfm"), (45, "v 45.pfm")):
+        want = ea.render(ea.arguments(ea.RECTILINEAR, 96, 64, 80.0, yaw=yaw, spline_degree=2), src)
+        assert (bits(read_pfm(tmp_path / name)) == bits(want)).all(), name
+
+
+@pytest.mark.gpu
+def test_eight_bit_input(cli, tmp_path):
+    rng = np.random.default_rng(9)
+    q = rng.integers(0, 256, (40, 80, 3), dtype=np.uint8)
+    (tmp_path / "in.ppm").write_bytes(b"P6\n# a comment\n80 40\n255\n" + q.tobytes())
+    r = cli(["--facet", "in.ppm", "spherical", "360", "0", "0", "0", "--projection", "spherical", "--hfov", "360",
+             "--width", "80", "--degree", "1", "--twine", "0", "--output", "out.ppm"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    raw = (tmp_path / "out.ppm").read_bytes()
+    assert raw.startswith(b"P6\n80 40\n255\n")
+    got = np.frombuffer(raw[len(b"P6\n80 40\n255\n"):], np.uint8).reshape(40, 80, 3)
+    img = (q.astype(np.float32) / np.float32(255)).astype(np.float32)
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 80, 40, 360.0), img, 1)
+    want = ea.render(ea.arguments(ea.SPHERICAL, 80, 40, 360.0, spline_degree=1), src)
+    assert (got == (np.clip(want, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint32)).all()

@@ -1,0 +1,159 @@
+// envutil_hip - envutil's command line on the MI355X path.
+//
+//   envutil_hip --facet pano.pfm spherical 360 0 0 0 --projection cubemap --hfov 90
+//               --width 1024 --spline_degree 3 --output cube.pfm
+//   envutil_hip --pto project.pto --output pano.pfm
+//   envutil_hip <fixed options> -          (pipe mode: one job per line of stdin)
+//
+// The same options, defaults and PTO handling as the reference's main() / core()
+// (envutil_main.cc:1634-1727, :1948-1982): include/eu_frontend.hpp fills project::args,
+// get_dispatch()->payload() renders (include/eu_dispatch.hpp -> libeu_hip.so), and the images
+// go through include/eu_image_io.hpp (PFM / PNM / PAM instead of OpenImageIO; no colour
+// management). Sources stay resident in HBM between the jobs of a pipe-mode session, as the
+// reference's asset_handler keeps them in RAM. There is no CPU rendering path: without an
+// MI355X every job fails with the library's error.
+#include <cstdio>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+#include "eu_frontend.hpp"
+#include "eu_image_io.hpp"
+#include "eu_imageprep.hpp"
+
+using namespace project;
+
+// tokenize (envutil_basic.cc:323-420): blanks separate, single or double quotes group, a
+// backslash inside quotes carries the quote sign
+static std::vector<std::string> tokenize(const std::string &s)
+{
+  std::vector<std::string> out;
+  std::string tok;
+  char quote = 0;
+  bool in_tok = false;
+  for (size_t i = 0; i < s.size(); i++) {
+    const char c = s[i];
+    if (quote) {
+      if (c == '\\' && i + 1 < s.size() && s[i + 1] == quote) { tok += quote; i++; }
+      else if (c == quote) { out.push_back(tok); tok.clear(); quote = 0; in_tok = false; }
+      else tok += c;
+    } else if (c == ' ' || c == '\t' || c == '\n' || c == '\r') {
+      if (in_tok) { out.push_back(tok); tok.clear(); in_tok = false; }
+    } else if (!in_tok && (c == '"' || c == '\'')) { quote = c; in_tok = true; }
+    else { tok += c; in_tok = true; }
+  }
+  if (in_tok) out.push_back(tok);
+  return out;
+}
+
+// image_series (envutil_basic.h:207-262): a format string with one %-sequence taking an integer
+static std::string series_name(const std::string &fmt, int index)
+{
+  std::vector<char> buf(fmt.size() + 32);
+  std::snprintf(buf.data(), buf.size(), fmt.c_str(), index);
+  return buf.data();
+}
+
+static int run_payload(const std::string &output)
+{
+  int ow = args.width, oh = args.height;
+  if (args.store_cropped) { ow = args.p_crop_x1 - args.p_crop_x0; oh = args.p_crop_y1 - args.p_crop_y0; }
+  std::vector<float> out(size_t(ow) * oh * args.nchannels);
+  args.p_output = out.data();
+  const int rc = get_dispatch()->payload(args.nchannels, args.twine ? 9 : 3, args.projection);
+  args.p_output = nullptr;
+  if (rc != 0) {
+    std::fprintf(stderr, "envutil_hip: render failed (%d): %s\n", rc, eu_hip_last_error());
+    return 1;
+  }
+  std::string err;
+  const bool cube = (args.projection == CUBEMAP || args.projection == BIATAN6) && !args.store_cropped;
+  if (!io::write_image(output, out.data(), ow, oh, args.nchannels, cube, err)) {
+    std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
+    return 1;
+  }
+  if (args.verbose) std::printf("saved %s (%d x %d x %d)\n", output.c_str(), ow, oh, args.nchannels);
+  return 0;
+}
+
+// core(), envutil_main.cc:1634-1727
+static int core(int argc, const char *const *argv)
+{
+  std::string err;
+  image_probe probe = [&](const std::string &name, image_info &info) {
+    std::string e;
+    return io::probe(name, info.width, info.height, info.nchannels, e);
+  };
+  if (!init_arguments(argc, argv, probe, err)) {
+    std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
+    return 2;
+  }
+  const auto *dp = static_cast<const hip_dispatch *>(get_dispatch());
+  if (args.verbose) std::printf("using %s (%s)\n", dp->hwy_target_name.c_str(), dp->hwy_target_str.c_str());
+  args.twine_setup();
+
+  // pixels of the facets that are not resident yet (asset_handler, environment.h:84-227)
+  std::vector<std::vector<float>> pixels(args.facet_spec_v.size());
+  for (size_t k = 0; k < args.facet_spec_v.size(); k++) {
+    facet_spec &f = args.facet_spec_v[k];
+    if (args.solo >= 0 && int(k) != args.solo) continue;
+    if (dp->resident.count(f.asset_key)) {
+      if (args.verbose) std::printf("asset %s is already resident\n", f.asset_key.c_str());
+      continue;
+    }
+    int w = 0, h = 0, nch = 0;
+    if (!io::read_image(f.filename, pixels[k], w, h, nch, err)) {
+      std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
+      return 2;
+    }
+    const bool cube = f.projection == CUBEMAP || f.projection == BIATAN6;
+    if (w != f.window_width || (cube ? h != 6 * w : h != f.window_height)) {
+      std::fprintf(stderr, "envutil_hip: %s is %d x %d, expected %d x %d\n", f.filename.c_str(), w, h,
+                   f.window_width, cube ? 6 * f.window_width : f.window_height);
+      return 2;
+    }
+    // PTO masks and lens crops edit the loaded pixels (environment.h:700-890)
+    if (!prepare_facet_pixels(f, pixels[k], nch, err)) {
+      std::fprintf(stderr, "envutil_hip: %s: %s\n", f.filename.c_str(), err.c_str());
+      return 2;
+    }
+    f.pixels = pixels[k].data();
+  }
+
+  if (!args.split.empty()) {
+    int rc = 0;
+    const int nfacets = args.nfacets;
+    for (int i = 0; i < nfacets && rc == 0; i++) {
+      if (i == args.solo) continue;
+      static_cast<facet_base &>(args) = args.facet_spec_v[size_t(i)];
+      args.single = i;
+      args.store_cropped = false;
+      args.output = series_name(args.split, i);
+      rc = run_payload(args.output);
+    }
+    return rc;
+  }
+  if (args.single != -1) args.store_cropped = false;
+  return run_payload(args.output);
+}
+
+int main(int argc, const char **argv)
+{
+  if (argc < 2) {
+    std::fprintf(stderr, "usage: envutil_hip <envutil options> (see README.md); a trailing '-' reads jobs from stdin\n");
+    return 2;
+  }
+  if (std::string(argv[argc - 1]) != "-") return core(argc, argv);
+  argc--;
+  int rc = 0;
+  std::string line;
+  while (std::getline(std::cin, line)) {
+    const std::vector<std::string> sv = tokenize(line);
+    if (sv.empty()) continue;
+    std::vector<const char *> av(argv, argv + argc);
+    for (const auto &t : sv) av.push_back(t.c_str());
+    const int r = core(int(av.size()), av.data());
+    if (r) rc = r;
+  }
+  return rc;
+}
