@@ -32,7 +32,8 @@ class Facet(C.Structure):
                 ("h", C.c_double), ("v", C.c_double), ("s", C.c_double),
                 ("shear_g", C.c_double), ("shear_t", C.c_double),
                 ("tr_x", C.c_double), ("tr_y", C.c_double), ("tr_z", C.c_double),
-                ("tp_y", C.c_double), ("tp_p", C.c_double), ("tp_r", C.c_double)]
+                ("tp_y", C.c_double), ("tp_p", C.c_double), ("tp_r", C.c_double),
+                ("mask_paint", C.c_int32)]
 
 
 class Container(C.Structure):
@@ -217,8 +218,9 @@ class facet_spec:
     (envutil_main.cc:957-960)."""
 
     def __init__(self, projection, width, height, hfov, nchannels=3, yaw=0.0,
-                 pitch=0.0, roll=0.0, brighten=1.0, window=None, lens=None, translation=None):
+                 pitch=0.0, roll=0.0, brighten=1.0, window=None, lens=None, translation=None, masked=-1):
         self.projection = projection
+        self.masked = masked            # --mask_for: -1 ordinary, 0 painted black, 1 painted white
         self.width, self.height = width, height
         self.hfov = hfov
         self.nchannels = nchannels
@@ -244,6 +246,7 @@ class facet_spec:
         f.has_lcp = int(any(self.lens.get(k, 0.0) != 0.0 for k in "abc"))
         f.tr_x, f.tr_y, f.tr_z = (self.translation.get(k, 0.0) for k in ("x", "y", "z"))
         f.tp_y, f.tp_p, f.tp_r = (math.radians(self.translation.get(k, 0.0)) for k in ("tp_y", "tp_p", "tp_r"))
+        f.mask_paint = self.masked + 1
         return f
 
 

@@ -162,6 +162,7 @@ void fill_src_dev(eu_source *s)
   d.gate0 = gt[0]; d.gate1 = gt[1];
   d.lower0 = lo[0]; d.upper0 = up[0]; d.lower1 = lo[1]; d.upper1 = up[1];
   d.brighten = (float)f.brighten;
+  d.mask_paint = f.mask_paint;
   d.recip_step = (float)(1.0 / f.step);
   d.mask_all = is_cube(f.projection) || (f.projection == EU_FISHEYE && f.hfov >= M_PI * 2.0);
   eu::weight_matrix(s->degree, d.wm);
@@ -235,6 +236,7 @@ int check_facet(const eu_facet *f)
 {
   if (!f) return fail(EU_ERR_ARGUMENT, "null facet");
   if (f->nchannels < 1 || f->nchannels > 4) return fail(EU_ERR_ARGUMENT, "nchannels must be 1..4");
+  if (f->mask_paint < 0 || f->mask_paint > 2) return fail(EU_ERR_ARGUMENT, "mask_paint must be 0, 1 or 2");
   if (f->projection < 0 || f->projection > EU_BIATAN6) return fail(EU_ERR_ARGUMENT, "unknown source projection");
   if (f->width <= 0 || f->height <= 0) return fail(EU_ERR_ARGUMENT, "empty source image");
   return EU_OK;
@@ -652,6 +654,13 @@ int launch_render(const eu_render_params *p, void *st)
   const char *r4env = getenv("EU_HIP_R4");
   const int r4mode = r4env ? atoi(r4env) : -1;
   const bool use_r4 = r4mode == 1 || (r4mode != 0 && is_cube(p->src.prj) && p->src.degree >= 2);
+  // a --mask_for job paints the facet at the inner evaluation: only the general kernels do that
+  if (p->src.mask_paint) {
+    eu_render_params q = *p;
+    q.direct = 1;                       // not the LDS-staged variant: it evaluates inline
+    g.launches++;
+    return eu_launch_render(&q, st);
+  }
   if (!force_v1 && use_r4) {
     // work list of the staged kernel (eu_render4.hip: chunk counters of the persistent kernel,
     // lists of the tiles left to the direct-gather kernel that follows it on the same stream)
@@ -1026,6 +1035,13 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   if (out_row_stride_bytes < min_stride) return fail(EU_ERR_ARGUMENT, "row stride smaller than a row");
   if (out_row_stride_bytes % sizeof(float)) return fail(EU_ERR_ARGUMENT, "row stride must be a multiple of 4 bytes");
   if (nsrc > 1 && trg->stage) return fail(EU_ERR_ARGUMENT, "stage outputs exist for single-facet jobs only");
+  for (int f = 0; f < nsrc; f++) {
+    if (!srcs[f]) return fail(EU_ERR_HANDLE, "null source");
+    // a masking job adapts channel counts with mono_t, which knows 1 and 2 output channels only
+    // (environment.h:1339: the reference asserts)
+    if (srcs[f]->fct.mask_paint && srcs[f]->nch != trg->nchannels && trg->nchannels > 2 && !trg->stage)
+      return fail(EU_ERR_ARGUMENT, "--mask_for: facets whose channel count differs from the target's need a 1- or 2-channel target");
+  }
   hipStream_t st = stream ? (hipStream_t)stream : g.stream;
   g.last_user = stream ? (hipStream_t)stream : nullptr;
   if (out_on_device) return render_on_device(trg, srcs, nsrc, out, out_row_stride_bytes, st);

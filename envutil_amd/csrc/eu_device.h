@@ -40,6 +40,7 @@ struct eu_src_dev {
   float win_x_off, win_y_off;
   float wex0, wex1, wex2, wex3;  // window extent narrowed for the compares
   float brighten;
+  int mask_paint;            // --mask_for: 0 pixels, 1 painted black, 2 painted white (masking.h:70-135)
   // pto_planar (environment.h:240-340), flags as process_geometry sets them
   int has_lcp, has_shift, has_shear;
   float lens_a, lens_b, lens_c, lens_d, lens_s, lens_h, lens_v;

@@ -399,6 +399,41 @@ template <int NCH, int DEG>
 __device__ __forceinline__ void eu_environment(const eu_src_dev &s, float rx, float ry,
                                                float rz, float *px);
 
+// --mask_for: the facet's inner evaluator is masking_t (1 or 3 channels: the paint,
+// unconditionally) or alpha_masking_t (2 or 4: colour = paint * alpha, alpha kept), masking.h:70-135
+template <int NCH>
+__device__ __forceinline__ void eu_paint(int mask_paint, float *px)
+{
+  const float paint = mask_paint == 2 ? 1.0f : 0.0f;
+  if constexpr (NCH == 1 || NCH == 3) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) px[c] = paint;
+  } else {
+    px[0] = paint * px[NCH - 1];
+    if constexpr (NCH == 4) { px[1] = px[0]; px[2] = px[0]; }
+  }
+}
+
+// mono_t, environment.h:1325-1383: the channel adaption of masking jobs, IN -> out_n in {1, 2}
+// (the host refuses other combinations, as the reference asserts on them). out has room for 4.
+template <int IN>
+__device__ __forceinline__ void eu_mono(int out_n, const float *in, float *out)
+{
+  if constexpr (IN == 1) { out[0] = in[0]; out[1] = 1.0f; }
+  else if constexpr (IN == 2) {
+    float v = in[0] / in[1];
+    if (in[1] == 0.0f) v = 0.0f;
+    out[0] = v;
+  } else if constexpr (IN == 3) { out[0] = in[0]; out[1] = 1.0f; }
+  else {
+    if (out_n == 1) {
+      float v = in[0] / in[3];
+      if (in[3] == 0.0f) v = 0.0f;
+      out[0] = v;
+    } else { out[0] = in[0]; out[1] = in[3]; }
+  }
+}
+
 // environment::eval behind the coordinate stage, for callers that already have
 // the source coordinate (the multi-facet synopsis computes it for the mask):
 // inner evaluation, repix, brighten on the OUTPUT layout (environment.h:1821-1842,
@@ -411,11 +446,13 @@ __device__ __forceinline__ void eu_environment_repix_at(const eu_src_dev &s, int
   if (hit) {
     if constexpr (DEG >= 0) eu_bspline<NCH, DEG>(s, sx, sy, raw);
     else eu_bspline_generic<NCH>(s, sx, sy, raw);
+    if (s.mask_paint) eu_paint<NCH>(s.mask_paint, raw);
   } else {
 #pragma unroll
     for (int c = 0; c < NCH; c++) raw[c] = 0.0f;
   }
-  eu_repix<NCH>(out_n, raw, px);
+  if (s.mask_paint) eu_mono<NCH>(out_n, raw, px);      // environment.h:1909-1957
+  else eu_repix<NCH>(out_n, raw, px);
   if (s.brighten != 1.0f) {
     const int ncol = (out_n == 2 || out_n == 4) ? out_n - 1 : out_n;
     for (int c = 0; c < ncol; c++) px[c] = px[c] * s.brighten;
@@ -439,6 +476,7 @@ __device__ __forceinline__ void eu_environment_at(const eu_src_dev &s, bool hit,
   if (hit) {
     if constexpr (DEG >= 0) eu_bspline<NCH, DEG>(s, sx, sy, px);
     else eu_bspline_generic<NCH>(s, sx, sy, px);
+    if (s.mask_paint) eu_paint<NCH>(s.mask_paint, px);
     // environment::eval, environment.h:1821-1842
     if (s.brighten != 1.0f) {
       constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;

@@ -187,6 +187,7 @@ struct hip_dispatch : public dispatch_base
     e.shear_g = f.shear_g; e.shear_t = f.shear_t;
     // PTO translation: such a facet is stepped by generic_stepper (envutil_payload.cc:2095-2110, :2145-2158)
     e.tr_x = f.tr_x; e.tr_y = f.tr_y; e.tr_z = f.tr_z; e.tp_y = f.tp_y; e.tp_p = f.tp_p; e.tp_r = f.tp_r;
+    e.mask_paint = f.masked + 1;     // --mask_for: -1 ordinary, 0 painted black, 1 painted white
     return e;
   }
 
@@ -195,15 +196,15 @@ struct hip_dispatch : public dispatch_base
     if (projection != args.projection) return EU_ERR_ARGUMENT;
     if ((ninputs == 9) != !args.twine_spread.empty()) return EU_ERR_ARGUMENT;
     if (args.tethered ? !args.p_screen_data : !args.p_output) return EU_ERR_ARGUMENT;
-    // outside this path: --mask_for (masking_t); PTO masks and lens crops edit the pixels at load
-    // time (prepare_facet_pixels) and must have been applied by the caller; an unknown synopsis is the reference's assert(false)
+    // PTO masks and lens crops edit the pixels at load time (prepare_facet_pixels) and must have
+    // been applied by the caller; an unknown synopsis is the reference's assert(false)
     // (envutil_payload.cc:2316-2318)
     if (args.synopsis != "panorama" && args.synopsis != "hdr_merge") return EU_ERR_ARGUMENT;
     // --split is the caller's loop over --single jobs (core(), envutil_main.cc:1676-1722)
     if (args.single >= int(args.facet_spec_v.size()) || args.solo >= int(args.facet_spec_v.size())) return EU_ERR_ARGUMENT;
     for (const auto &fct : args.facet_spec_v)
-      if (((fct.has_pto_mask || fct.has_lens_crop) && !fct.pixels_prepared &&
-           !resident.count(fct.asset_key)) || fct.masked != -1) return EU_ERR_UNSUPPORTED;
+      if ((fct.has_pto_mask || fct.has_lens_crop) && !fct.pixels_prepared && !resident.count(fct.asset_key))
+        return EU_ERR_UNSUPPORTED;
     std::vector<eu_source *> srcs;
     for (size_t fi = 0; fi < args.facet_spec_v.size(); fi++) {
       // --solo: only that facet takes part (fuse(), envutil_payload.cc:2085-2127)

@@ -77,6 +77,11 @@ typedef struct eu_facet {
    * tr_x/y/z != 0 is stepped by generic_stepper over tf_ex_facet (envutil_payload.cc:2095-2110,
    * :2145-2158; geometry.h:1850-1941) instead of the target projection's own stepper.            */
   double  tr_x, tr_y, tr_z, tp_y, tp_p, tp_r;
+  /* --mask_for (facet_spec::masked, envutil_main.cc:1077-1092; masking.h:70-135): 0 ordinary
+   * pixels (masked == -1), 1 the facet is painted black (masked == 0), 2 white (masked == 1).
+   * Facets of 1 / 3 channels yield the paint, facets with alpha paint * alpha and their alpha;
+   * a target with another channel count takes them through mono_t (1 or 2 channels only).   */
+  int32_t mask_paint;
 } eu_facet;
 
 typedef struct eu_source eu_source;   /* opaque: coefficients resident in HBM */

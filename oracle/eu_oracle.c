@@ -1661,6 +1661,17 @@ static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
     return 0;
   }
   ev_eval(&m->ev, crd3[0], crd3[1], px);
+  if (m->src->mask_paint) {
+    /* the facet's evaluator is masking_t (1 or 3 channels: the paint, unconditionally) or
+     * alpha_masking_t (2 or 4: colour = paint * alpha, alpha kept), masking.h:70-135 */
+    const int n = m->src->spl.nch;
+    const float paint = m->src->mask_paint == 2 ? 1.0f : 0.0f;
+    if (n == 1 || n == 3) for (int c = 0; c < n; c++) px[c] = paint;
+    else {
+      px[0] = paint * px[n - 1];
+      if (n == 4) px[1] = px[2] = px[0];
+    }
+  }
   return 1;
 }
 
@@ -1697,6 +1708,23 @@ static void repix(int in_n, int out_n, const float *in, float *out)
   }
 }
 
+/* mono_t, environment.h:1325-1383: the channel adaption of masking jobs (1 or 2 output channels:
+ * the colour channels of a mask are equal, so one stands for all; alpha stays associated).
+ * Returns 0 for the combinations the reference asserts on. */
+static int mono(int in_n, int out_n, const float *in, float *out)
+{
+  if (in_n == out_n) { for (int c = 0; c < in_n; c++) out[c] = in[c]; return 1; }
+  if (out_n != 1 && out_n != 2) return 0;
+  if (in_n == 1) { out[0] = in[0]; out[1] = 1.0f; }
+  else if (in_n == 2) { out[0] = in[0] / in[1]; if (in[1] == 0.0f) out[0] = 0.0f; }
+  else if (in_n == 3) { out[0] = in[0]; if (out_n == 2) out[1] = 1.0f; }
+  else {
+    if (out_n == 1) { out[0] = in[0]; out[0] /= in[3]; if (in[3] == 0.0f) out[0] = 0.0f; }
+    else { out[0] = in[0]; out[1] = in[3]; }
+  }
+  return 1;
+}
+
 /* environment::eval (environment.h:1821-1842) for a target with out_n channels:
  * inner evaluation, channel adaption, then brighten on the OUTPUT layout */
 static void env_eval(const mount_t *m, const float *ray, int out_n, float *px, float *dbg)
@@ -1704,7 +1732,8 @@ static void env_eval(const mount_t *m, const float *ray, int out_n, float *px, f
   float raw[4];
   int in_n = m->src->spl.nch;
   mount_eval(m, ray, raw, dbg);
-  repix(in_n, out_n, raw, px);
+  if (m->src->mask_paint) mono(in_n, out_n, raw, px);      /* environment.h:1909-1957 */
+  else repix(in_n, out_n, raw, px);
   if (m->brighten != 1.0f) {
     int ncol = (out_n == 2 || out_n == 4) ? out_n - 1 : out_n;
     for (int c = 0; c < ncol; c++) px[c] *= m->brighten;

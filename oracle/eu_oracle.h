@@ -70,6 +70,9 @@ typedef struct {
   /* cubemap sources: cubemap_view_t members, environment.h:1425-1436 */
   float refc_md, model_to_px;
   int section_px;
+  /* --mask_for (envutil_main.cc:1077-1092): 0 ordinary pixels, 1 the facet is painted black
+   * (fct.masked == 0), 2 white (fct.masked == 1): masking_t / alpha_masking_t, masking.h:70-135 */
+  int mask_paint;
 } euo_source;
 
 /* the target + job parameters travelling in envutil's global 'args' */

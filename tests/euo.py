@@ -37,7 +37,7 @@ class Source(C.Structure):
                 ("tp_y", C.c_double), ("tp_p", C.c_double), ("tp_r", C.c_double),
                 ("spl", Spline),
                 ("refc_md", C.c_float), ("model_to_px", C.c_float),
-                ("section_px", C.c_int)]
+                ("section_px", C.c_int), ("mask_paint", C.c_int)]
 
 
 class Job(C.Structure):

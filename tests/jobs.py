@@ -45,7 +45,7 @@ class OracleSource:
 
     def __init__(self, prj, width, height, hfov_deg, pixels, spline_degree,
                  prefilter_degree=None, yaw=0.0, pitch=0.0, roll=0.0, brighten=1.0,
-                 support_min=8, tile=64, lens=None, window=None, translation=None):
+                 support_min=8, tile=64, lens=None, window=None, translation=None, masked=-1):
         """window = (window_width, window_height, x_offset, y_offset): `pixels` is that
         window of a width x height frame (a cropped PTO image, envutil_basic.h:447-470)"""
         if prefilter_degree is None:
@@ -62,6 +62,7 @@ class OracleSource:
             s.window_width, s.window_height, s.window_x_offset, s.window_y_offset = window
         s.yaw, s.pitch, s.roll = (math.radians(v) for v in (yaw, pitch, roll))
         s.brighten = brighten
+        s.mask_paint = masked + 1
         s.step = euo.lib().euo_get_step(prj, width, height, hf)
         if lens:
             # PTO lens parameters a, b, c (radial), h, v (shift), g, t (shear)

@@ -141,6 +141,16 @@ def test_pto_with_mask_and_crop(cli, tmp_path):
     want = ea.render(ea.arguments(ea.SPHERICAL, 300, 150, 360.0, spline_degree=1), [sa, sb], 4)
     assert (bits(out) == bits(want)).all()
     assert (out[..., 3] == 0).any() and (out[..., 3] == 1).any()
+    # --mask_for 1: where the fisheye image shows in that stitch (white * alpha), the other facet black
+    r = cli(["--pto", "two.pto", "--output", "m1.pfm", "--degree", "1", "--twine", "0", "--mask_for", "1"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    fa.masked, fb.masked = 0, 1
+    sa.update_facet(fa)
+    sb.update_facet(fb)
+    wantm = ea.render(ea.arguments(ea.SPHERICAL, 300, 150, 360.0, spline_degree=1), [sa, sb], 4)
+    got = read_pfm(tmp_path / "m1.pfm")
+    assert (bits(got) == bits(wantm)).all()
+    assert (got[..., 0] == got[..., 1]).all() and got[..., 0].max() == 1.0
 
 
 @pytest.mark.gpu
