@@ -20,6 +20,7 @@
 
 #include <array>
 #include <cmath>
+#include <fstream>
 #include <map>
 #include <string>
 #include <vector>
@@ -127,10 +128,14 @@ struct arguments : public facet_base
   // arguments::twine_setup, envutil_main.cc:1405-1616: --twine N (N >= 0) is taken as given;
   // -1 (the command line's default) derives twine and twine_width from the magnification
   // smallest facet step / target step; then twine_density, then make_spread
-  // (envutil_main.cc:1253-1355). A twf file (tap table from disk) is file I/O: not here.
-  void twine_setup()
+  // (envutil_main.cc:1253-1355) - or, with --twf_file, the tap table read from that text file
+  // (read_twf_file, envutil_main.cc:1357-1403: x y weight triples, x and y scaled by twine_width,
+  // the weights divided by their sum under --twine_normalize). Returns false when the file
+  // cannot be read (the reference asserts).
+  bool twine_setup()
   {
     twine_spread.clear();
+    if (!twf_file.empty()) twine = 1;
     if (twine != -1) {
       if (twine < 0) twine = 0;
     } else {
@@ -151,11 +156,30 @@ struct arguments : public facet_base
       }
     }
     if (twine_density != 1.0f) twine = int(std::round(twine * twine_density));
-    if (twine <= 0) return;
+    if (!twf_file.empty()) {
+      std::ifstream ifs(twf_file);
+      if (!ifs.good()) return false;
+      double sum = 0.0;
+      std::array<float, 3> c;
+      while (ifs.good()) {
+        ifs >> c[0] >> c[1] >> c[2];
+        if (ifs.eof()) break;
+        if (ifs.fail()) return false;              // not a number: the reference would loop forever
+        twine_spread.push_back(c);
+        sum += c[2];
+      }
+      for (auto &t : twine_spread) {
+        t[0] *= twine_width; t[1] *= twine_width;
+        if (twine_normalize) t[2] /= sum;
+      }
+      return !twine || !twine_spread.empty();
+    }
+    if (twine <= 0) return true;
     std::vector<float> t(3 * size_t(twine < 2 ? 4 : twine * twine));
     int n = eu_hip_make_spread(twine, twine, twine_width, twine_sigma, twine_threshold, t.data(),
                                int(t.size() / 3));
     for (int i = 0; i < n; i++) twine_spread.push_back({ t[3 * i], t[3 * i + 1], t[3 * i + 2] });
+    return true;
   }
 };
 

@@ -9,7 +9,7 @@
 // eu_dispatch.hpp. What the reference gets from OpenImageIO here is an image file's width,
 // height and channel count (facet_base::get_image_metrics, envutil_basic.h:546-589): the host
 // passes a callback for that (`image_probe`). Everything that is file I/O or colour
-// management stays out: twf files, colour-space options (accepted, stored nowhere), the
+// management stays out: colour-space options (accepted, stored nowhere), the
 // --oiio pass-through options, "metadata" projections of --photo images.
 //
 // Errors: the reference asserts or exits; this returns false and a message.
@@ -198,7 +198,6 @@ inline bool init_arguments(int argc, const char *const *argv, const image_probe 
   a.brighten = fl("--brighten", 1.0f);
   a.projection_str = str("--projection", "rectilinear");
   if (bad) return false;
-  if (!a.twf_file.empty()) { err = "--twf_file: tap tables from disk are file I/O, outside this front end"; return false; }
   if (a.prefilter_degree < 0) a.prefilter_degree = a.spline_degree;
   a.projection = projection_t(projection_index(a.projection_str));
   if (a.projection == PRJ_NONE) { err = "unknown projection " + a.projection_str; return false; }

@@ -322,3 +322,19 @@ def test_single_command_line_to_pixels(demo, tmp_path):
                                               translation=tr), spline_degree=1)
     a.single_oracle = o1
     assert fnv1a(jobs.oracle_render(a, [o0, o1])) == got
+
+
+def test_twf_file_is_the_tap_table(demo, tmp_path):
+    """--twf_file (read_twf_file, envutil_main.cc:1357-1403): x y weight triples from a text file; x and y
+    are scaled by twine_width, the weights divided by their sum under --twine_normalize; twine becomes 1"""
+    (tmp_path / "k.twf").write_text("-0.25 -0.25 1\n0.25 -0.25 2\n-0.25 0.25 3\n0.25 0.25 2\n")
+    base = ["--facet", "pano.tif", "spherical", "360", "0", "0", "0", "--output", "o.exr", "--width", "256",
+            "--twf_file", "k.twf", "--twine_width", "1.5"]
+    j = demo(base, {"pano.tif": (4000, 2000, 3)}, cwd=str(tmp_path))
+    assert j["ok"] and j["twine"] == 1
+    w = np.float32(1.5)
+    want = [[f32(np.float32(x) * w), f32(np.float32(y) * w), float(k)] for x, y, k in
+            ((-0.25, -0.25, 1), (0.25, -0.25, 2), (-0.25, 0.25, 3), (0.25, 0.25, 2))]
+    assert j["spread"] == want
+    j = demo(base + ["--twine_normalize"], {"pano.tif": (4000, 2000, 3)}, cwd=str(tmp_path))
+    assert [t[2] for t in j["spread"]] == [f32(np.float32(k) / 8.0) for k in (1, 2, 3, 2)]

@@ -90,7 +90,10 @@ static int core(int argc, const char *const *argv)
   }
   const auto *dp = static_cast<const hip_dispatch *>(get_dispatch());
   if (args.verbose) std::printf("using %s (%s)\n", dp->hwy_target_name.c_str(), dp->hwy_target_str.c_str());
-  args.twine_setup();
+  if (!args.twine_setup()) {
+    std::fprintf(stderr, "envutil_hip: cannot read the tap table %s\n", args.twf_file.c_str());
+    return 2;
+  }
 
   // pixels of the facets that are not resident yet (asset_handler, environment.h:84-227)
   std::vector<std::vector<float>> pixels(args.facet_spec_v.size());
