@@ -808,8 +808,10 @@ int eu_hip_facet_alpha(float *pixels, int width, int height, int nchannels, cons
   try { alpha.resize(size_t(width) * height); } catch (...) { return fail(EU_ERR_MEMORY, "facet_alpha: host memory"); }
   eu::facet_alpha(alpha.data(), width, height, ps.data(), int(ps.size()), crop_kind, crop_x0, crop_x1, crop_y0, crop_y1);
   if (pixels)
-    for (size_t i = 0; i < alpha.size(); i++)
-      for (int c = 0; c < nchannels; c++) pixels[i * nchannels + c] = pixels[i * nchannels + c] * alpha[i];
+    eu::parallel_rows(height, [&](int y0, int y1) {
+      for (size_t i = size_t(y0) * width; i < size_t(y1) * width; i++)
+        for (int c = 0; c < nchannels; c++) pixels[i * nchannels + c] = pixels[i * nchannels + c] * alpha[i];
+    });
   if (alpha_out) memcpy(alpha_out, alpha.data(), alpha.size() * sizeof(float));
   return EU_OK;
 }

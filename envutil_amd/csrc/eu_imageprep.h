@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstddef>
+#include <thread>
 #include <vector>
 
 namespace eu {
@@ -92,11 +93,50 @@ inline void binomial_line(const float *in, float *out, int n, ptrdiff_t stride)
 
 struct mask_polygon { int n; const float *x, *y; };
 
+// fn(y0, y1) over [0, n) on up to 16 host threads (rows are independent in every pass below)
+template <class F>
+inline void parallel_rows(int n, F fn)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt < 1 ? 1 : nt > 16 ? 16 : nt;
+  if (n < 256 || nt == 1) { fn(0, n); return; }
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nt; t++) {
+    const int y0 = int((long long)n * t / nt), y1 = int((long long)n * (t + 1) / nt);
+    if (y1 > y0) pool.emplace_back([=] { fn(y0, y1); });
+  }
+  for (auto &th : pool) th.join();
+}
+
+// axis 1 of the binomial, row by row: output row t is the slot-ordered sum of the five rows
+// t - 2 + ((s - t) mod 5) (REFLECT beyond the ends) - per element the same operations in the same
+// order as binomial_line down a column, but along contiguous memory
+inline void binomial_rows(const float *in, float *out, int w, int h, int y0, int y1)
+{
+  static const float kf[5] = { float(1.0 / 16.0), float(4.0 / 16.0), float(6.0 / 16.0), float(4.0 / 16.0),
+                               float(1.0 / 16.0) };
+  for (int t = y0; t < y1; t++) {
+    int k = ((0 - t) % 5 + 5) % 5;
+    float *o = out + size_t(t) * w;
+    {
+      const float *r = in + size_t(reflect_index(t - 2 + k, h)) * w;
+      const float kk = kf[k];
+      for (int x = 0; x < w; x++) o[x] = r[x] * kk;
+    }
+    for (int s = 1; s < 5; s++) {
+      k = k == 4 ? 0 : k + 1;
+      const float *r = in + size_t(reflect_index(t - 2 + k, h)) * w;
+      const float kk = kf[k];
+      for (int x = 0; x < w; x++) o[x] += r[x] * kk;
+    }
+  }
+}
+
 // alpha plane of a facet (w x h floats): environment.h:727-843
 inline void facet_alpha(float *alpha, int w, int h, const mask_polygon *polys, int npolys, int crop_kind,
                         int cx0, int cx1, int cy0, int cy1)
 {
-  for (size_t i = 0; i < size_t(w) * h; i++) alpha[i] = 1.0f;
+  parallel_rows(h, [&](int y0, int y1) { for (size_t i = size_t(y0) * w; i < size_t(y1) * w; i++) alpha[i] = 1.0f; });
   for (int p = 0; p < npolys; p++)
     fill_polygon(polys[p].x, polys[p].y, polys[p].n, 0, 0, w, h,
                  [&](int x, int y) { alpha[size_t(y) * w + x] = 0.0f; });
@@ -104,7 +144,8 @@ inline void facet_alpha(float *alpha, int w, int h, const mask_polygon *polys, i
     // elliptic crop of a fisheye image
     const float a = float(std::fabs(double(cx1 - cx0)) / 2.0), b = float(std::fabs(double(cy1 - cy0)) / 2.0);
     const float mx = float((cx0 + cx1) / 2.0), my = float((cy0 + cy1) / 2.0);
-    for (int y = 0; y < h; y++) {
+    parallel_rows(h, [&](int y0, int y1) {
+    for (int y = y0; y < y1; y++) {
       const float dy = std::fabs(float(y) - my);
       if (dy > b) {
         for (int x = 0; x < w; x++) alpha[size_t(y) * w + x] = 0.0f;
@@ -117,15 +158,20 @@ inline void facet_alpha(float *alpha, int w, int h, const mask_polygon *polys, i
         if (dx > xmargin) alpha[size_t(y) * w + x] = 0.0f;
       }
     }
+    });
   } else if (crop_kind == 1) {
-    for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++)
-        if (x < cx0 || x >= cx1 || y < cy0 || y >= cy1) alpha[size_t(y) * w + x] = 0.0f;
+    parallel_rows(h, [&](int y0, int y1) {
+      for (int y = y0; y < y1; y++)
+        for (int x = 0; x < w; x++)
+          if (x < cx0 || x >= cx1 || y < cy0 || y >= cy1) alpha[size_t(y) * w + x] = 0.0f;
+    });
   }
   // convolve(alpha, alpha, {REFLECT, REFLECT}, binomial, 2): axis 0, then axis 1 on the result
   std::vector<float> tmp(size_t(w) * h);
-  for (int y = 0; y < h; y++) binomial_line(alpha + size_t(y) * w, tmp.data() + size_t(y) * w, w, 1);
-  for (int x = 0; x < w; x++) binomial_line(tmp.data() + x, alpha + x, h, w);
+  parallel_rows(h, [&](int y0, int y1) {
+    for (int y = y0; y < y1; y++) binomial_line(alpha + size_t(y) * w, tmp.data() + size_t(y) * w, w, 1);
+  });
+  parallel_rows(h, [&](int y0, int y1) { binomial_rows(tmp.data(), alpha, w, h, y0, y1); });
 }
 
 }  // namespace eu

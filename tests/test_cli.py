@@ -183,3 +183,42 @@ def test_eight_bit_input(cli, tmp_path):
     src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 80, 40, 360.0), img, 1)
     want = ea.render(ea.arguments(ea.SPHERICAL, 80, 40, 360.0, spline_degree=1), src)
     assert (got == (np.clip(want, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_split_recreates_every_facet(cli, tmp_path):
+    """--split (core(), envutil_main.cc:1676-1722): one --single job per facet, each facet's geometry
+    taken over as the target and the stitch of all facets rendered into it"""
+    a, b = synth(120, 90, 3, 3), synth(100, 100, 3, 4)
+    write_pfm(tmp_path / "a.pfm", a)
+    write_pfm(tmp_path / "b.pfm", b)
+    (tmp_path / "two.pto").write_text(
+        'p f2 w200 h100 v360 n"TIFF"\n'
+        'i w120 h90 f0 v60 y5 p2 r1 a0.01 b-0.02 c0.01 n"a.pfm"\n'
+        'i w100 h100 f0 v75 y40 p-5 r0 n"b.pfm"\n')
+    r = cli(["--pto", "two.pto", "--split", "facet_%02d.pfm", "--degree", "1", "--twine", "0"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    lens = dict(a=0.01, b=-0.02, c=0.01)
+    fa = ea.facet_spec(ea.RECTILINEAR, 120, 90, 60.0, yaw=5, pitch=2, roll=1, lens=lens)
+    fb = ea.facet_spec(ea.RECTILINEAR, 100, 100, 75.0, yaw=40, pitch=-5, roll=0)
+    srcs = [ea.Source.load(fa, a, 1), ea.Source.load(fb, b, 1)]
+    for i, f in enumerate((fa, fb)):
+        want = ea.render(ea.arguments.for_single(f, spline_degree=1), srcs, 3)
+        got = read_pfm(tmp_path / f"facet_{i:02d}.pfm")
+        assert got.shape == want.shape and (bits(got) == bits(want)).all(), i
+
+
+@pytest.mark.gpu
+def test_pto_crop_window_output(cli, tmp_path):
+    """a p-line with a crop (S clause): the output file holds the crop window only (store_cropped)"""
+    img = synth(160, 80, 3, 6)
+    write_pfm(tmp_path / "pano.pfm", img)
+    (tmp_path / "c.pto").write_text(
+        'p f2 w240 h120 v360 S40,200,10,90 n"TIFF"\n'
+        'i w160 h80 f4 v360 y20 p0 r0 n"pano.pfm"\n')
+    r = cli(["--pto", "c.pto", "--output", "crop.pfm", "--degree", "3", "--twine", "0"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 160, 80, 360.0, yaw=20), img, 3)
+    want = ea.render(ea.arguments(ea.SPHERICAL, 240, 120, 360.0, spline_degree=3, crop=(40, 200, 10, 90)), src)
+    got = read_pfm(tmp_path / "crop.pfm")
+    assert got.shape == (80, 160, 3) and (bits(got) == bits(want)).all()
