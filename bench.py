@@ -114,7 +114,14 @@ def main():
     dev = torch.device(f"cuda:{local}")
     ea.lib().eu_hip_init(local)
     dist = None
-    if world > 1:
+    # EU_BENCH_FORCE_DIST=1: take the N-rank code path (RCCL process group, broadcast of the source into
+    # the library's buffer, barrier, all-reduce of the time, gather) with ONE rank - a check of the
+    # transport plumbing on a one-GPU box, not a measurement
+    force_dist = world == 1 and os.environ.get("EU_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -150,7 +157,7 @@ def main():
             del host
         else:
             s1 = ea.Source.alloc(fct, degree)
-        if world > 1:
+        if dist is not None:
             ptr, n = s1.device_ptr()
             buf = torch.as_tensor(_DevBuf(ptr, n), device=dev)
             if rehearse:
