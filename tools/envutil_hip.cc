@@ -146,6 +146,23 @@ int main(int argc, const char **argv)
     std::fprintf(stderr, "usage: envutil_hip <envutil options> (see README.md); a trailing '-' reads jobs from stdin\n");
     return 2;
   }
+  for (int i = 1; i < argc; i++)
+    if (std::string(argv[i]) == "--help" || std::string(argv[i]) == "-h") {
+      std::puts(
+        "envutil_hip - envutil's reprojection on an MI355X (options as in envutil, envutil_main.cc:190-372)\n"
+        "  source:   --facet IMAGE PROJECTION HFOV YAW PITCH ROLL (repeatable) | --pto FILE [--pto_line LINE]\n"
+        "            projections: spherical cylindrical rectilinear stereographic fisheye cubemap biatan6\n"
+        "            --solo N  --single N  --split FORMAT(%d)  --mask_for N  --synopsis panorama|hdr_merge\n"
+        "  target:   --output FILE  --projection P  --hfov DEG  --width W  --height H  --yaw --pitch --roll DEG\n"
+        "            --x0 --x1 --y0 --y1 (extent instead of hfov)  --nchannels N  --brighten F\n"
+        "  spline:   --degree D  --prefilter D  --support_min PX  --tile_size PX (cubemap sources)\n"
+        "  twining:  --twine N (-1: automatic)  --twine_width F  --twine_density F  --twine_max N\n"
+        "            --twine_sigma F  --twine_threshold F  --twine_normalize  --twine_precise  --twf_file FILE\n"
+        "  images:   .pfm (float), .pgm .ppm .pnm (8 / 16 bit), .pam (8 / 16 bit, alpha); a name with one %s\n"
+        "            stands for six cube faces: left right top bottom front back\n"
+        "  -v verbose; a trailing '-' reads one job per line from stdin (sources stay resident in HBM)");
+      return 0;
+    }
   if (std::string(argv[argc - 1]) != "-") return core(argc, argv);
   argc--;
   int rc = 0;
