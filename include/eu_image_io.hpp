@@ -13,6 +13,9 @@
 //   .pgm .ppm .pnm  binary PNM (P5 / P6), 8 or 16 bit: value / maxval
 //   .pam            P7 (GRAYSCALE, GRAYSCALE_ALPHA, RGB, RGB_ALPHA), 8 or 16 bit: the integer
 //                   format with an alpha channel
+//   .hdr .pic       Radiance RGBE pictures (32-bit_rle_rgbe, -Y h +X w; flat or run-length encoded
+//                   scanlines on input, flat on output), the usual container of lat/lon environment maps;
+//                   mantissa * 2^(exponent - 136) as in the widely used rgbe.c that OpenImageIO follows
 // Writing integer formats follows OpenImageIO's float -> unsigned conversion: clamp to [0, 1],
 // scale by maxval, add 0.5, truncate. Cubemaps: one image of aspect 1:6, or six files named by a
 // format string with one %s, filled with left, right, top, bottom, front, back (cubeface_series,
@@ -22,6 +25,7 @@
 #ifndef EU_IMAGE_IO_HPP
 #define EU_IMAGE_IO_HPP
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +41,7 @@ struct header
   int maxval = 0;          // 0: float samples
   bool little_endian = true;   // PFM
   bool bottom_up = false;
+  bool rgbe = false;           // Radiance picture: 4-byte RGBE pixels, flat or run-length encoded scanlines
   long data_offset = 0;
 };
 
@@ -64,9 +69,33 @@ inline bool token(FILE *f, std::string &t)
   return true;   // exactly one whitespace character behind the token has been consumed
 }
 
+// Radiance header: "#?RADIANCE" (or "#?RGBE"), lines of NAME=value, an empty line, then "-Y h +X w"
+inline bool read_rgbe_header(FILE *f, header &h, std::string &err)
+{
+  char line[512];
+  bool format_ok = false;
+  for (;;) {
+    if (!std::fgets(line, sizeof line, f)) { err = "truncated Radiance header"; return false; }
+    if (line[0] == '\n' || (line[0] == '\r' && line[1] == '\n')) break;
+    if (!std::strncmp(line, "FORMAT=", 7)) format_ok = !std::strncmp(line + 7, "32-bit_rle_rgbe", 15);
+  }
+  if (!format_ok) { err = "Radiance picture without FORMAT=32-bit_rle_rgbe"; return false; }
+  if (!std::fgets(line, sizeof line, f)) { err = "truncated Radiance header"; return false; }
+  if (std::sscanf(line, "-Y %d +X %d", &h.height, &h.width) != 2) { err = "only the standard orientation -Y h +X w is read"; return false; }
+  h.nchannels = 3; h.maxval = 0; h.rgbe = true;
+  if (h.width <= 0 || h.height <= 0) { err = "unsupported image geometry"; return false; }
+  h.data_offset = std::ftell(f);
+  return true;
+}
+
 inline bool read_header(FILE *f, header &h, std::string &err)
 {
   std::string magic, t;
+  {
+    const int c0 = std::fgetc(f), c1 = std::fgetc(f);
+    if (c0 == '#' && c1 == '?') return read_rgbe_header(f, h, err);
+    std::rewind(f);
+  }
   if (!token(f, magic)) { err = "empty file"; return false; }
   try {
     if (magic == "PF" || magic == "Pf" || magic == "PF4") {
@@ -99,7 +128,7 @@ inline bool read_header(FILE *f, header &h, std::string &err)
         else if (t == "MAXVAL") h.maxval = std::stoi(v);
       }
     } else {
-      err = "not a PFM / PNM / PAM file (magic '" + magic + "')";
+      err = "not a PFM / PNM / PAM / Radiance file (magic '" + magic + "')";
       return false;
     }
   } catch (...) { err = "malformed header"; return false; }
@@ -162,7 +191,49 @@ inline bool read_one(const std::string &name, header &h, float *dst, std::string
   h = g;
   const size_t row = size_t(h.width) * h.nchannels;
   bool ok = true;
-  if (h.maxval == 0) {
+  if (h.rgbe) {
+    std::vector<uint8_t> sl(size_t(h.width) * 4);
+    for (int y = 0; y < h.height && ok; y++) {
+      uint8_t b4[4];
+      ok = std::fread(b4, 1, 4, f) == 4;
+      if (!ok) break;
+      if (b4[0] == 2 && b4[1] == 2 && !(b4[2] & 0x80) && ((int(b4[2]) << 8) | b4[3]) == h.width && h.width >= 8 && h.width < 32768) {
+        // new run-length encoding: the four components one after the other
+        for (int c = 0; c < 4 && ok; c++) {
+          int x = 0;
+          while (x < h.width && ok) {
+            int n = std::fgetc(f);
+            if (n == EOF) { ok = false; break; }
+            if (n > 128) {
+              n -= 128;
+              const int v = std::fgetc(f);
+              if (v == EOF || x + n > h.width) { ok = false; break; }
+              for (int i = 0; i < n; i++) sl[size_t(x++) * 4 + c] = uint8_t(v);
+            } else {
+              if (n == 0 || x + n > h.width) { ok = false; break; }
+              for (int i = 0; i < n; i++) {
+                const int v = std::fgetc(f);
+                if (v == EOF) { ok = false; break; }
+                sl[size_t(x++) * 4 + c] = uint8_t(v);
+              }
+            }
+          }
+        }
+      } else {
+        // flat scanline (the first pixel is already read)
+        std::memcpy(sl.data(), b4, 4);
+        ok = std::fread(sl.data() + 4, 1, sl.size() - 4, f) == sl.size() - 4;
+      }
+      float *d = dst + size_t(y) * row;
+      for (int x = 0; x < h.width; x++) {
+        const uint8_t *p = sl.data() + size_t(x) * 4;
+        if (p[3]) {
+          const float fexp = std::ldexp(1.0f, int(p[3]) - (128 + 8));
+          d[3 * x] = p[0] * fexp; d[3 * x + 1] = p[1] * fexp; d[3 * x + 2] = p[2] * fexp;
+        } else d[3 * x] = d[3 * x + 1] = d[3 * x + 2] = 0.0f;
+      }
+    }
+  } else if (h.maxval == 0) {
     const uint16_t one = 1;
     const bool host_little = *reinterpret_cast<const uint8_t *>(&one) == 1;
     for (int y = 0; y < h.height && ok; y++) {
@@ -223,6 +294,25 @@ inline bool write_one(const std::string &name, const float *src, int width, int 
     const bool host_little = *reinterpret_cast<const uint8_t *>(&one) == 1;
     std::fprintf(f, "%s\n%d %d\n%s\n", nch == 1 ? "Pf" : nch == 3 ? "PF" : "PF4", width, height, host_little ? "-1.0" : "1.0");
     for (int y = height - 1; y >= 0 && ok; y--) ok = std::fwrite(src + size_t(y) * row, 4, row, f) == row;
+  } else if (ext == "hdr" || ext == "pic") {
+    if (nch != 3) { std::fclose(f); err = name + ": a Radiance picture holds 3 channels"; return false; }
+    std::fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", height, width);
+    std::vector<uint8_t> sl(size_t(width) * 4);
+    for (int y = 0; y < height && ok; y++) {
+      const float *sp = src + size_t(y) * row;
+      for (int x = 0; x < width; x++) {
+        const float r = sp[3 * x], g = sp[3 * x + 1], b = sp[3 * x + 2];
+        float v = r > g ? r : g;
+        v = b > v ? b : v;
+        uint8_t *p = sl.data() + size_t(x) * 4;
+        if (!(v >= 1e-32f)) { p[0] = p[1] = p[2] = p[3] = 0; continue; }     // also NaN and negatives
+        int e;
+        const float m = std::frexp(v, &e) * 256.0f / v;
+        p[0] = uint8_t(r > 0.0f ? r * m : 0.0f); p[1] = uint8_t(g > 0.0f ? g * m : 0.0f);
+        p[2] = uint8_t(b > 0.0f ? b * m : 0.0f); p[3] = uint8_t(e + 128);
+      }
+      ok = std::fwrite(sl.data(), 1, sl.size(), f) == sl.size();
+    }
   } else if (ext == "pgm" || ext == "ppm" || ext == "pnm" || ext == "pam") {
     const bool pam = ext == "pam";
     if (!pam && nch != 1 && nch != 3) { std::fclose(f); err = name + ": PNM holds 1 or 3 channels; use .pam or .pfm"; return false; }
@@ -245,7 +335,7 @@ inline bool write_one(const std::string &name, const float *src, int width, int 
     }
   } else {
     std::fclose(f);
-    err = name + ": output formats are .pfm, .pgm, .ppm, .pnm, .pam";
+    err = name + ": output formats are .pfm, .hdr, .pgm, .ppm, .pnm, .pam";
     return false;
   }
   ok = std::fclose(f) == 0 && ok;

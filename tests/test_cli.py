@@ -222,3 +222,137 @@ def test_pto_crop_window_output(cli, tmp_path):
     want = ea.render(ea.arguments(ea.SPHERICAL, 240, 120, 360.0, spline_degree=3, crop=(40, 200, 10, 90)), src)
     got = read_pfm(tmp_path / "crop.pfm")
     assert got.shape == (80, 160, 3) and (bits(got) == bits(want)).all()
+
+
+# ---------------------------------------------------------------------------------- image files (CPU)
+
+def rgbe_decode(q):
+    """(h, w, 4) uint8 -> float32, mantissa * 2^(e - 136), zero exponent -> 0 (rgbe.c)"""
+    e = q[..., 3].astype(np.int32)
+    f = np.ldexp(np.float32(1.0), e - 136).astype(np.float32)
+    out = (q[..., :3].astype(np.float32) * f[..., None]).astype(np.float32)
+    out[e == 0] = 0
+    return out
+
+
+def rgbe_encode(img):
+    v = img.max(axis=2)
+    m, e = np.frexp(v.astype(np.float32))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = (m.astype(np.float32) * np.float32(256.0) / v).astype(np.float32)
+    q = np.zeros(img.shape[:2] + (4,), np.uint8)
+    ok = v >= np.float32(1e-32)
+    for c in range(3):
+        q[..., c] = np.where(ok, np.maximum(img[..., c], 0) * scale, 0).astype(np.uint8)
+    q[..., 3] = np.where(ok, e + 128, 0).astype(np.uint8)
+    return q
+
+
+def rle_scanline(row):
+    """new-style Radiance run-length encoding of one (w, 4) uint8 scanline"""
+    w = row.shape[0]
+    out = bytearray([2, 2, w >> 8, w & 255])
+    for c in range(4):
+        comp = row[:, c].tolist()
+        x = 0
+        while x < w:
+            run = 1
+            while x + run < w and run < 127 and comp[x + run] == comp[x]:
+                run += 1
+            if run >= 4:
+                out += bytes([128 + run, comp[x]])
+                x += run
+            else:
+                n = 1
+                while x + n < w and n < 128 and not (x + n + 3 < w and comp[x + n] == comp[x + n + 1] == comp[x + n + 2] == comp[x + n + 3]):
+                    n += 1
+                out += bytes([n]) + bytes(comp[x:x + n])
+                x += n
+    return bytes(out)
+
+
+@pytest.fixture(scope="module")
+def io_demo():
+    exe = os.path.join(ROOT, "envutil_amd", "build", "io_demo")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "csrc", "io_demo.cc"), "-o", exe])
+
+    def run(src, dst, cwd):
+        return subprocess.run([exe, src, dst], capture_output=True, text=True, cwd=str(cwd), timeout=60)
+    return run
+
+
+def test_radiance_pictures(io_demo, tmp_path):
+    rng = np.random.default_rng(4)
+    w, h = 40, 12
+    q = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    q[..., 3] = rng.integers(100, 150, (h, w))
+    q[2, 5:30] = q[2, 5]                       # runs for the encoder
+    q[3, :, 3] = 0                             # zero exponents: black
+    head = b"#?RADIANCE\n# made by a test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (h, w)
+    (tmp_path / "flat.hdr").write_bytes(head + q.tobytes())
+    (tmp_path / "rle.hdr").write_bytes(head + b"".join(rle_scanline(q[y]) for y in range(h)))
+    want = rgbe_decode(q)
+    for name in ("flat.hdr", "rle.hdr"):
+        r = io_demo(name, "out.pfm", tmp_path)
+        assert r.returncode == 0 and r.stdout.split() == [str(w), str(h), "3"], r.stderr
+        assert (bits(read_pfm(tmp_path / "out.pfm")) == bits(want)).all(), name
+    # writing: float -> RGBE as rgbe.c does it, flat scanlines
+    img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(8.0)).astype(np.float32)
+    img[0, 0] = 0
+    img[0, 1] = (1e-35, 0, 0)
+    write_pfm(tmp_path / "in.pfm", img)
+    r = io_demo("in.pfm", "out.hdr", tmp_path)
+    assert r.returncode == 0, r.stderr
+    raw = (tmp_path / "out.hdr").read_bytes()
+    body = raw.split(b"-Y %d +X %d\n" % (h, w), 1)[1]
+    assert raw.startswith(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n")
+    assert (np.frombuffer(body, np.uint8).reshape(h, w, 4) == rgbe_encode(img)).all()
+    # a truncated picture and a foreign orientation are errors, not crashes
+    (tmp_path / "cut.hdr").write_bytes(head + q.tobytes()[:100])
+    assert io_demo("cut.hdr", "x.pfm", tmp_path).returncode == 1
+    (tmp_path / "rot.hdr").write_bytes(head.replace(b"-Y", b"+Y") + q.tobytes())
+    assert io_demo("rot.hdr", "x.pfm", tmp_path).returncode == 1
+
+
+def test_integer_and_float_files_round_trip(io_demo, tmp_path):
+    rng = np.random.default_rng(8)
+    for n, name in ((1, "g.pfm"), (3, "c.pfm"), (4, "a.pfm")):
+        img = rng.random((9, 14, n), dtype=np.float32)
+        write_pfm(tmp_path / name, img if n > 1 else img[..., 0])
+        r = io_demo(name, "o_" + name, tmp_path)
+        assert r.returncode == 0 and r.stdout.split() == ["14", "9", str(n)], r.stderr
+        assert (bits(read_pfm(tmp_path / ("o_" + name))) == bits(img)).all()
+    # big-endian PFM in, 16-bit PAM out and back
+    img = rng.random((5, 7, 4), dtype=np.float32)
+    (tmp_path / "be.pfm").write_bytes(b"PF4\n7 5\n1.0\n" + np.ascontiguousarray(img[::-1], ">f4").tobytes())
+    assert io_demo("be.pfm", "q.pam", tmp_path).returncode == 0
+    assert io_demo("q.pam", "back.pfm", tmp_path).returncode == 0
+    q16 = (np.clip(img, 0, 1) * np.float32(65535) + np.float32(0.5)).astype(np.uint32)
+    assert (bits(read_pfm(tmp_path / "back.pfm")) == bits(q16.astype(np.float32) / np.float32(65535))).all()
+    # 2-channel images need PAM; PFM refuses them
+    write2 = tmp_path / "ga.pam"
+    write2.write_bytes(b"P7\nWIDTH 3\nHEIGHT 2\nDEPTH 2\nMAXVAL 255\nTUPLTYPE GRAYSCALE_ALPHA\nENDHDR\n" + bytes(range(12)))
+    assert io_demo("ga.pam", "ga2.pam", tmp_path).returncode == 0
+    assert io_demo("ga.pam", "ga.pfm", tmp_path).returncode == 1
+
+
+@pytest.mark.gpu
+def test_radiance_environment_map(cli, tmp_path):
+    """the usual case: a lat/lon .hdr environment map to a cubemap, written as .hdr again"""
+    rng = np.random.default_rng(12)
+    w, h = 128, 64
+    q = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    q[..., 3] = rng.integers(120, 136, (h, w))
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    (tmp_path / "env.hdr").write_bytes(head + b"".join(rle_scanline(q[y]) for y in range(h)))
+    r = cli(["--facet", "env.hdr", "spherical", "360", "0", "0", "0", "--projection", "cubemap", "--hfov", "90",
+             "--width", "32", "--degree", "3", "--twine", "0", "--output", "cube.hdr"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    img = rgbe_decode(q)
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, w, h, 360.0), img, 3)
+    want = ea.render(ea.arguments(ea.CUBEMAP, 32, 192, 90.0, spline_degree=3), src)
+    raw = (tmp_path / "cube.hdr").read_bytes()
+    body = raw.split(b"-Y 192 +X 32\n", 1)[1]
+    assert (np.frombuffer(body, np.uint8).reshape(192, 32, 4) == rgbe_encode(want)).all()

@@ -158,7 +158,7 @@ int main(int argc, const char **argv)
         "  spline:   --degree D  --prefilter D  --support_min PX  --tile_size PX (cubemap sources)\n"
         "  twining:  --twine N (-1: automatic)  --twine_width F  --twine_density F  --twine_max N\n"
         "            --twine_sigma F  --twine_threshold F  --twine_normalize  --twine_precise  --twf_file FILE\n"
-        "  images:   .pfm (float), .pgm .ppm .pnm (8 / 16 bit), .pam (8 / 16 bit, alpha); a name with one %s\n"
+        "  images:   .pfm .hdr (float), .pgm .ppm .pnm (8 / 16 bit), .pam (8 / 16 bit, alpha); a name with one %s\n"
         "            stands for six cube faces: left right top bottom front back\n"
         "  -v verbose; a trailing '-' reads one job per line from stdin (sources stay resident in HBM)");
       return 0;
