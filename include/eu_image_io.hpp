@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -274,7 +275,8 @@ inline bool read_image(const std::string &name, std::vector<float> &pixels, int 
   header h;
   if (!probe_one(faces[0], h, err)) return false;
   const size_t per = size_t(h.width) * h.height * h.nchannels;
-  pixels.resize(per * faces.size());
+  try { pixels.resize(per * faces.size()); }
+  catch (const std::exception &) { err = name + ": not enough host memory for " + std::to_string(h.width) + " x " + std::to_string(h.height) + " pixels"; return false; }
   for (size_t i = 0; i < faces.size(); i++)
     if (!read_one(faces[i], h, pixels.data() + i * per, err)) return false;
   width = h.width; height = h.height * int(faces.size()); nchannels = h.nchannels;
