@@ -338,3 +338,23 @@ def test_twf_file_is_the_tap_table(demo, tmp_path):
     assert j["spread"] == want
     j = demo(base + ["--twine_normalize"], {"pano.tif": (4000, 2000, 3)}, cwd=str(tmp_path))
     assert [t[2] for t in j["spread"]] == [f32(np.float32(k) / 8.0) for k in (1, 2, 3, 2)]
+
+
+def test_k_lines_become_mask_polygons(demo, tmp_path):
+    """k-lines (envutil_main.cc:827-905): the polygon of an exclude mask goes to its image's facet_spec, the
+    facet gains an alpha channel and a mask-specific asset key; an S clause is the lens crop"""
+    (tmp_path / "m.pto").write_text(
+        'p f2 w300 h150 v360 n"TIFF"\n'
+        'i w200 h150 f0 v70 y10 p5 r2 n"a.tif"\n'
+        'i w160 h160 f3 v170 y-100 p-20 r0 S10,150,12,148 n"b.tif"\n'
+        'k i0 t0 p"30 20 120.5 25 140 110 40 100"\n'
+        'k i0 t1 p"1 2 3 4 5 6"\n')
+    j = demo(["--pto", "m.pto", "--output", "o.tif", "--mask_for", "1"],
+             {"a.tif": (200, 150, 3), "b.tif": (160, 160, 3)}, cwd=str(tmp_path))
+    assert j["ok"] and j["nchannels"] == 4
+    fa, fb = j["facets"]
+    assert fa["has_pto_mask"] == 1 and fa["nchannels"] == 4 and fa["asset_key"] == "a.tif.m.pto.0.1"
+    assert fa["masks"] == [{"variant": 0, "xy": [30, 20, 120.5, 25, 140, 110, 40, 100]},
+                           {"variant": 1, "xy": [1, 2, 3, 4, 5, 6]}]
+    assert fb["has_lens_crop"] == 1 and fb["lens_crop"] == [10, 150, 12, 148] and fb["nchannels"] == 4 and fb["masks"] == []
+    assert (fa["masked"], fb["masked"]) == (0, 1)
