@@ -10,7 +10,7 @@
 // height and channel count (facet_base::get_image_metrics, envutil_basic.h:546-589): the host
 // passes a callback for that (`image_probe`). Everything that is file I/O or colour
 // management stays out: colour-space options (accepted, stored nowhere), the
-// --oiio pass-through options, "metadata" projections of --photo images.
+// --oiio pass-through options. --photo images take projection and hfov from the metadata the probe reports.
 //
 // Errors: the reference asserts or exits; this returns false and a message.
 // Header-only; link with -leu_hip (get_extent / get_step are the library's).
@@ -28,7 +28,9 @@
 
 namespace project {
 
-struct image_info { int width = 0, height = 0, nchannels = 0; };
+// projection / hfov: the image's "Projection" and "Hfov" (degrees) metadata where the file carries them
+// (envutil writes both into its output, save_array, envutil_basic.h:770-772); empty / negative: absent
+struct image_info { int width = 0, height = 0, nchannels = 0; std::string projection; double hfov = -1.0; };
 typedef std::function<bool(const std::string &filename, image_info &info)> image_probe;
 
 static const char *const projection_name[] = { "spherical", "cylindrical", "rectilinear", "stereographic",
@@ -223,8 +225,9 @@ inline bool init_arguments(int argc, const char *const *argv, const image_probe 
   double p_hfov = 0.0, p_eev = 0.0;
   float eev_sum = 0.0f;
   int eev_count = 0;
+  image_info info;      // of the image probed last (its metadata serve --photo / "metadata" facets)
   auto metrics = [&](facet_spec &f) -> bool {
-    image_info info;
+    info = image_info();
     if (!probe || !probe(f.filename, info) || info.width <= 0 || info.height <= 0 || info.nchannels <= 0) {
       err = "failed to open facet image '" + f.filename + "'";
       return false;
@@ -369,16 +372,24 @@ inline bool init_arguments(int argc, const char *const *argv, const image_probe 
     facet_spec f;
     f.filename = v[0];
     f.projection_str = v[1];
-    if (f.projection_str == "metadata") { err = "--photo / projection 'metadata' needs image metadata: outside this front end"; return false; }
-    f.projection = projection_t(projection_index(f.projection_str));
-    if (f.projection == PRJ_NONE) { err = "unknown facet projection " + f.projection_str; return false; }
+    // facet_spec::init (envutil_main.cc:104-176): hfov -1 and the projection "metadata" (what --photo
+    // passes for both) are read from the image's metadata, with 65 degrees / rectilinear where absent
+    // (get_image_metrics, envutil_basic.h:589-625)
+    double hfov_deg = 0.0;
     try {
-      f.hfov = std::stod(v[2]) * (M_PI / 180.0);
+      hfov_deg = std::stod(v[2]);
       f.yaw = std::stod(v[3]) * (M_PI / 180.0);
       f.pitch = std::stod(v[4]) * (M_PI / 180.0);
       f.roll = std::stod(v[5]) * (M_PI / 180.0);
     } catch (...) { err = "parse of 'facet' argument failed: " + v[0]; return false; }
+    const bool read_hfov = hfov_deg == -1.0;
+    if (hfov_deg <= 0.0 && !read_hfov) { err = "facet hfov invalid: " + v[2]; return false; }
     if (!metrics(f)) return false;
+    if (read_hfov) hfov_deg = info.hfov >= 0.0 ? double(float(info.hfov)) : 65.0;
+    if (f.projection_str == "metadata") f.projection_str = info.projection.empty() ? "rectilinear" : info.projection;
+    f.hfov = hfov_deg * (M_PI / 180.0);
+    f.projection = projection_t(projection_index(f.projection_str));
+    if (f.projection == PRJ_NONE) { err = "unknown facet projection " + f.projection_str; return false; }
     f.facet_no = a.nfacets++;
     f.process_geometry();
     f.asset_key = f.filename;

@@ -44,7 +44,14 @@ struct header
   bool bottom_up = false;
   bool rgbe = false;           // Radiance picture: 4-byte RGBE pixels, flat or run-length encoded scanlines
   long data_offset = 0;
+  // "Projection" / "Hfov" (degrees) as envutil's save_array attaches them to its output
+  // (envutil_basic.h:770-772): header lines Projection=... / Hfov=... of a Radiance picture, comment
+  // lines "# Projection: ..." / "# Hfov: ..." of a PNM / PAM header; PFM has no room for them
+  std::string projection;
+  double hfov = -1.0;
 };
+
+struct metadata { std::string projection; double hfov = -1.0; };
 
 inline std::string lower_ext(const std::string &name)
 {
@@ -56,14 +63,31 @@ inline std::string lower_ext(const std::string &name)
 }
 
 // next whitespace-separated token of a PNM header; '#' starts a comment up to the line's end
-inline bool token(FILE *f, std::string &t)
+inline void note_metadata(const std::string &line, char sep, header &h)
+{
+  const size_t p = line.find(sep);
+  if (p == std::string::npos) return;
+  std::string key = line.substr(0, p), val = line.substr(p + 1);
+  while (!key.empty() && (key[0] == ' ' || key[0] == '#')) key.erase(0, 1);
+  while (!val.empty() && (val[0] == ' ')) val.erase(0, 1);
+  while (!val.empty() && (val.back() == '\n' || val.back() == '\r' || val.back() == ' ')) val.pop_back();
+  if (key == "Projection") h.projection = val;
+  else if (key == "Hfov") { try { h.hfov = std::stod(val); } catch (...) {} }
+}
+
+inline bool token(FILE *f, std::string &t, header *meta = nullptr)
 {
   t.clear();
   int c;
   for (;;) {
     c = std::fgetc(f);
     if (c == EOF) return false;
-    if (c == '#') { while ((c = std::fgetc(f)) != EOF && c != '\n') {} continue; }
+    if (c == '#') {
+      std::string line;
+      while ((c = std::fgetc(f)) != EOF && c != '\n') line += char(c);
+      if (meta) note_metadata(line, ':', *meta);
+      continue;
+    }
     if (c != ' ' && c != '\t' && c != '\n' && c != '\r') break;
   }
   while (c != EOF && c != ' ' && c != '\t' && c != '\n' && c != '\r') { t += char(c); c = std::fgetc(f); }
@@ -79,6 +103,7 @@ inline bool read_rgbe_header(FILE *f, header &h, std::string &err)
     if (!std::fgets(line, sizeof line, f)) { err = "truncated Radiance header"; return false; }
     if (line[0] == '\n' || (line[0] == '\r' && line[1] == '\n')) break;
     if (!std::strncmp(line, "FORMAT=", 7)) format_ok = !std::strncmp(line + 7, "32-bit_rle_rgbe", 15);
+    else note_metadata(line, '=', h);
   }
   if (!format_ok) { err = "Radiance picture without FORMAT=32-bit_rle_rgbe"; return false; }
   if (!std::fgets(line, sizeof line, f)) { err = "truncated Radiance header"; return false; }
@@ -97,32 +122,32 @@ inline bool read_header(FILE *f, header &h, std::string &err)
     if (c0 == '#' && c1 == '?') return read_rgbe_header(f, h, err);
     std::rewind(f);
   }
-  if (!token(f, magic)) { err = "empty file"; return false; }
+  if (!token(f, magic, &h)) { err = "empty file"; return false; }
   try {
     if (magic == "PF" || magic == "Pf" || magic == "PF4") {
       h.nchannels = magic == "Pf" ? 1 : magic == "PF" ? 3 : 4;
-      if (!token(f, t)) { err = "truncated header"; return false; }
+      if (!token(f, t, &h)) { err = "truncated header"; return false; }
       h.width = std::stoi(t);
-      if (!token(f, t)) { err = "truncated header"; return false; }
+      if (!token(f, t, &h)) { err = "truncated header"; return false; }
       h.height = std::stoi(t);
-      if (!token(f, t)) { err = "truncated header"; return false; }
+      if (!token(f, t, &h)) { err = "truncated header"; return false; }
       h.little_endian = std::stod(t) < 0.0;
       h.maxval = 0;
       h.bottom_up = true;
     } else if (magic == "P5" || magic == "P6") {
       h.nchannels = magic == "P5" ? 1 : 3;
-      if (!token(f, t)) { err = "truncated header"; return false; }
+      if (!token(f, t, &h)) { err = "truncated header"; return false; }
       h.width = std::stoi(t);
-      if (!token(f, t)) { err = "truncated header"; return false; }
+      if (!token(f, t, &h)) { err = "truncated header"; return false; }
       h.height = std::stoi(t);
-      if (!token(f, t)) { err = "truncated header"; return false; }
+      if (!token(f, t, &h)) { err = "truncated header"; return false; }
       h.maxval = std::stoi(t);
     } else if (magic == "P7") {
       for (;;) {
-        if (!token(f, t)) { err = "truncated header"; return false; }
+        if (!token(f, t, &h)) { err = "truncated header"; return false; }
         if (t == "ENDHDR") break;
         std::string v;
-        if (!token(f, v)) { err = "truncated header"; return false; }
+        if (!token(f, v, &h)) { err = "truncated header"; return false; }
         if (t == "WIDTH") h.width = std::stoi(v);
         else if (t == "HEIGHT") h.height = std::stoi(v);
         else if (t == "DEPTH") h.nchannels = std::stoi(v);
@@ -166,7 +191,8 @@ inline bool cubeface_names(const std::string &fmt, std::vector<std::string> &nam
 
 // facet_base::get_image_metrics (envutil_basic.h:546-589): a name with a percent sign is a set
 // of six cube faces and reports the metrics of the first
-inline bool probe(const std::string &name, int &width, int &height, int &nchannels, std::string &err)
+inline bool probe(const std::string &name, int &width, int &height, int &nchannels, std::string &err,
+                  metadata *meta = nullptr)
 {
   header h;
   std::vector<std::string> faces;
@@ -174,6 +200,7 @@ inline bool probe(const std::string &name, int &width, int &height, int &nchanne
   if (series && !cubeface_names(name, faces)) { err = "a format string needs exactly one %s: " + name; return false; }
   if (!probe_one(series ? faces[0] : name, h, err)) return false;
   width = h.width; height = h.height; nchannels = h.nchannels;
+  if (meta) { meta->projection = h.projection; meta->hfov = h.hfov; }
   return true;
 }
 
@@ -283,7 +310,8 @@ inline bool read_image(const std::string &name, std::vector<float> &pixels, int 
   return true;
 }
 
-inline bool write_one(const std::string &name, const float *src, int width, int height, int nch, std::string &err)
+inline bool write_one(const std::string &name, const float *src, int width, int height, int nch, std::string &err,
+                      const metadata *meta = nullptr)
 {
   const std::string ext = lower_ext(name);
   FILE *f = std::fopen(name.c_str(), "wb");
@@ -298,7 +326,9 @@ inline bool write_one(const std::string &name, const float *src, int width, int 
     for (int y = height - 1; y >= 0 && ok; y--) ok = std::fwrite(src + size_t(y) * row, 4, row, f) == row;
   } else if (ext == "hdr" || ext == "pic") {
     if (nch != 3) { std::fclose(f); err = name + ": a Radiance picture holds 3 channels"; return false; }
-    std::fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", height, width);
+    std::fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n");
+    if (meta && !meta->projection.empty()) std::fprintf(f, "Projection=%s\nHfov=%.9g\n", meta->projection.c_str(), meta->hfov);
+    std::fprintf(f, "\n-Y %d +X %d\n", height, width);
     std::vector<uint8_t> sl(size_t(width) * 4);
     for (int y = 0; y < height && ok; y++) {
       const float *sp = src + size_t(y) * row;
@@ -321,8 +351,14 @@ inline bool write_one(const std::string &name, const float *src, int width, int 
     const int maxval = pam ? 65535 : 255;
     if (pam) {
       static const char *const tt[5] = { "", "GRAYSCALE", "GRAYSCALE_ALPHA", "RGB", "RGB_ALPHA" };
-      std::fprintf(f, "P7\nWIDTH %d\nHEIGHT %d\nDEPTH %d\nMAXVAL %d\nTUPLTYPE %s\nENDHDR\n", width, height, nch, maxval, tt[nch]);
-    } else std::fprintf(f, "%s\n%d %d\n%d\n", nch == 1 ? "P5" : "P6", width, height, maxval);
+      std::fprintf(f, "P7\n");
+      if (meta && !meta->projection.empty()) std::fprintf(f, "# Projection: %s\n# Hfov: %.9g\n", meta->projection.c_str(), meta->hfov);
+      std::fprintf(f, "WIDTH %d\nHEIGHT %d\nDEPTH %d\nMAXVAL %d\nTUPLTYPE %s\nENDHDR\n", width, height, nch, maxval, tt[nch]);
+    } else {
+      std::fprintf(f, "%s\n", nch == 1 ? "P5" : "P6");
+      if (meta && !meta->projection.empty()) std::fprintf(f, "# Projection: %s\n# Hfov: %.9g\n", meta->projection.c_str(), meta->hfov);
+      std::fprintf(f, "%d %d\n%d\n", width, height, maxval);
+    }
     std::vector<uint8_t> buf(row * (pam ? 2 : 1));
     for (int y = 0; y < height && ok; y++) {
       const float *s = src + size_t(y) * row;
@@ -348,16 +384,19 @@ inline bool write_one(const std::string &name, const float *src, int width, int 
 // save_array (envutil_basic.h:710-815): a cubemap target whose output name is a format string
 // goes to six face images, everything else to one file
 inline bool write_image(const std::string &name, const float *src, int width, int height, int nch,
-                        bool cubemap, std::string &err)
+                        bool cubemap, std::string &err, const metadata *meta = nullptr)
 {
   std::vector<std::string> faces;
   if (cubemap && name.find('%') != std::string::npos && cubeface_names(name, faces)) {
     if (height != 6 * width) { err = "a cubemap is 1:6"; return false; }
+    // save_array writes the six faces as rectilinear images (envutil_basic.h:741-757)
+    metadata face_meta;
+    if (meta) { face_meta.projection = "rectilinear"; face_meta.hfov = meta->hfov; }
     for (int i = 0; i < 6; i++)
-      if (!write_one(faces[size_t(i)], src + size_t(i) * width * width * nch, width, width, nch, err)) return false;
+      if (!write_one(faces[size_t(i)], src + size_t(i) * width * width * nch, width, width, nch, err, meta ? &face_meta : nullptr)) return false;
     return true;
   }
-  return write_one(name, src, width, height, nch, err);
+  return write_one(name, src, width, height, nch, err, meta);
 }
 
 }  // namespace io

@@ -177,8 +177,9 @@ def test_eight_bit_input(cli, tmp_path):
              "--width", "80", "--degree", "1", "--twine", "0", "--output", "out.ppm"], tmp_path)
     assert r.returncode == 0, r.stderr
     raw = (tmp_path / "out.ppm").read_bytes()
-    assert raw.startswith(b"P6\n80 40\n255\n")
-    got = np.frombuffer(raw[len(b"P6\n80 40\n255\n"):], np.uint8).reshape(40, 80, 3)
+    # the target's projection and hfov travel as comment lines, as envutil attaches them to its output
+    assert raw.startswith(b"P6\n# Projection: spherical\n# Hfov: 360\n80 40\n255\n")
+    got = np.frombuffer(raw.split(b"80 40\n255\n", 1)[1], np.uint8).reshape(40, 80, 3)
     img = (q.astype(np.float32) / np.float32(255)).astype(np.float32)
     src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 80, 40, 360.0), img, 1)
     want = ea.render(ea.arguments(ea.SPHERICAL, 80, 40, 360.0, spline_degree=1), src)
@@ -356,3 +357,32 @@ def test_radiance_environment_map(cli, tmp_path):
     raw = (tmp_path / "cube.hdr").read_bytes()
     body = raw.split(b"-Y 192 +X 32\n", 1)[1]
     assert (np.frombuffer(body, np.uint8).reshape(192, 32, 4) == rgbe_encode(want)).all()
+
+
+@pytest.mark.gpu
+def test_photo_reads_the_metadata_envutil_writes(cli, tmp_path):
+    """--photo IMAGE = --facet IMAGE metadata -1 0 0 0 (envutil_main.cc:916-927): projection and hfov come from the
+    image's "Projection" / "Hfov" metadata - which the program attaches to what it writes - or default to
+    rectilinear, 65 degrees"""
+    img = synth(256, 128, 3, 21)
+    write_pfm(tmp_path / "pano.pfm", img)
+    r = cli(["--facet", "pano.pfm", "spherical", "360", "0", "0", "0", "--projection", "fisheye", "--hfov", "140",
+             "--width", "120", "--height", "120", "--degree", "1", "--twine", "0", "--output", "view.hdr"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    raw = (tmp_path / "view.hdr").read_bytes()
+    assert b"FORMAT=32-bit_rle_rgbe\nProjection=fisheye\nHfov=140\n\n-Y 120 +X 120\n" in raw[:200]
+    r = cli(["--photo", "view.hdr", "--projection", "spherical", "--hfov", "360", "--width", "200", "--degree", "1",
+             "--twine", "0", "--output", "back.pfm"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    body = raw.split(b"-Y 120 +X 120\n", 1)[1]
+    view = rgbe_decode(np.frombuffer(body, np.uint8).reshape(120, 120, 4))
+    src = ea.Source.load(ea.facet_spec(ea.FISHEYE, 120, 120, 140.0), view, 1)
+    want = ea.render(ea.arguments(ea.SPHERICAL, 200, 100, 360.0, spline_degree=1), src)
+    assert (bits(read_pfm(tmp_path / "back.pfm")) == bits(want)).all()
+    # a file without metadata: rectilinear, 65 degrees
+    r = cli(["--photo", "pano.pfm", "--projection", "spherical", "--hfov", "360", "--width", "200", "--degree", "1",
+             "--twine", "0", "--output", "p65.pfm"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    src65 = ea.Source.load(ea.facet_spec(ea.RECTILINEAR, 256, 128, 65.0), img, 1)
+    want65 = ea.render(ea.arguments(ea.SPHERICAL, 200, 100, 360.0, spline_degree=1), src65)
+    assert (bits(read_pfm(tmp_path / "p65.pfm")) == bits(want65)).all()

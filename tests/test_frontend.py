@@ -358,3 +358,16 @@ def test_k_lines_become_mask_polygons(demo, tmp_path):
                            {"variant": 1, "xy": [1, 2, 3, 4, 5, 6]}]
     assert fb["has_lens_crop"] == 1 and fb["lens_crop"] == [10, 150, 12, 148] and fb["nchannels"] == 4 and fb["masks"] == []
     assert (fa["masked"], fb["masked"]) == (0, 1)
+
+
+def test_photo_and_metadata_facets_default_to_rectilinear_65(demo):
+    """--photo IMAGE is --facet IMAGE metadata -1 0 0 0; without metadata in the file: rectilinear, 65 degrees
+    (get_image_metrics, envutil_basic.h:589-625); an hfov <= 0 other than -1 is refused"""
+    j = demo(["--photo", "p.tif", "--output", "o.tif"], {"p.tif": (300, 200, 3)})
+    assert j["ok"]
+    f = j["facets"][0]
+    assert f["projection"] == ea.RECTILINEAR and f["hfov"] == 65.0 * RAD and (f["yaw"], f["pitch"], f["roll"]) == (0, 0, 0)
+    j = demo(["--facet", "p.tif", "metadata", "40", "10", "0", "0", "--output", "o.tif"], {"p.tif": (300, 200, 3)})
+    assert j["ok"] and j["facets"][0]["projection"] == ea.RECTILINEAR and j["facets"][0]["hfov"] == 40.0 * RAD
+    j = demo(["--facet", "p.tif", "spherical", "0", "0", "0", "0", "--output", "o.tif"], {"p.tif": (300, 200, 3)})
+    assert j["ok"] is False and "hfov invalid" in j["error"]

@@ -68,7 +68,11 @@ static int run_payload(const std::string &output)
   }
   std::string err;
   const bool cube = (args.projection == CUBEMAP || args.projection == BIATAN6) && !args.store_cropped;
-  if (!io::write_image(output, out.data(), ow, oh, args.nchannels, cube, err)) {
+  // save_array attaches the target's projection and hfov (degrees) to the file (envutil_basic.h:770-772)
+  io::metadata meta;
+  meta.projection = projection_name[args.projection];
+  meta.hfov = (180.0 / M_PI) * args.hfov;
+  if (!io::write_image(output, out.data(), ow, oh, args.nchannels, cube, err, &meta)) {
     std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
     return 1;
   }
@@ -82,7 +86,10 @@ static int core(int argc, const char *const *argv)
   std::string err;
   image_probe probe = [&](const std::string &name, image_info &info) {
     std::string e;
-    return io::probe(name, info.width, info.height, info.nchannels, e);
+    io::metadata m;
+    if (!io::probe(name, info.width, info.height, info.nchannels, e, &m)) return false;
+    info.projection = m.projection; info.hfov = m.hfov;
+    return true;
   };
   if (!init_arguments(argc, argv, probe, err)) {
     std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
@@ -150,7 +157,7 @@ int main(int argc, const char **argv)
     if (std::string(argv[i]) == "--help" || std::string(argv[i]) == "-h") {
       std::puts(
         "envutil_hip - envutil's reprojection on an MI355X (options as in envutil, envutil_main.cc:190-372)\n"
-        "  source:   --facet IMAGE PROJECTION HFOV YAW PITCH ROLL (repeatable) | --pto FILE [--pto_line LINE]\n"
+        "  source:   --facet IMAGE PROJECTION HFOV YAW PITCH ROLL (repeatable) | --photo IMAGE | --pto FILE [--pto_line LINE]\n"
         "            projections: spherical cylindrical rectilinear stereographic fisheye cubemap biatan6\n"
         "            --solo N  --single N  --split FORMAT(%d)  --mask_for N  --synopsis panorama|hdr_merge\n"
         "  target:   --output FILE  --projection P  --hfov DEG  --width W  --height H  --yaw --pitch --roll DEG\n"
