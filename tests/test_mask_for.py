@@ -146,3 +146,39 @@ def test_mask_of_a_cubemap_facet_and_refusals():
     s3 = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 64, 32, 360.0, nchannels=3, masked=1), jobs.synth_image(64, 32, 3), 1)
     with pytest.raises(ea.EuError):
         ea.render(args, s3, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_random_mask_jobs_bit_identical(seed):
+    """--mask_for over the randomised facets of the round-2 fuzz (all mounts, lens polynomials, translated facets,
+    alpha holes, brighten), twining, both synopsis modes, every target projection, mono_t where channel counts differ"""
+    import test_gpu_fuzz_round2 as F
+    rng = np.random.default_rng(91000 + seed)
+    for k in range(5):
+        out_n = int(rng.integers(1, 5))
+        degree = int(rng.choice([0, 1, 1, 2, 3]))
+        nf = int(rng.choice([1, 2, 3, 4]))
+        # facets of the target's channel count, or - for one- and two-channel targets - of any (mono_t)
+        fn = [out_n if (out_n > 2 or rng.random() < 0.5) else int(rng.integers(1, 5)) for _ in range(nf)]
+        facets = [F.draw_facet(rng, fn[i], degree, seed * 1000 + 10 * k + i) for i in range(nf)]
+        os_, gs = [f[0] for f in facets], [f[1] for f in facets]
+        which = int(rng.integers(nf))
+        set_mask_for(os_, gs, which)
+        kw = dict(spline_degree=degree, twine=int(rng.choice([0, 0, 2, 3])),
+                  synopsis=str(rng.choice(["panorama", "panorama", "hdr_merge"])))
+        tprj = F.GENERIC_TRG[rng.integers(len(F.GENERIC_TRG))]
+        if tprj in (ea.CUBEMAP, ea.BIATAN6):
+            tw = int(rng.integers(8, 40)); th, thf = 6 * tw, 90.0
+        else:
+            tw, th = int(rng.integers(8, 160)), int(rng.integers(8, 80))
+            thf = float(rng.uniform(30.0, {ea.RECTILINEAR: 130.0, ea.STEREOGRAPHIC: 280.0}.get(tprj, 360.0)))
+        a = ea.arguments(tprj, tw, th, thf, yaw=float(rng.uniform(-180, 180)), pitch=float(rng.uniform(-60, 60)),
+                         roll=float(rng.uniform(-30, 30)), **kw)
+        what = f"seed {seed} job {k}: facets {fn} -> {out_n} channels, mask_for {which}, deg {degree} {kw} target {tprj} {tw}x{th}"
+        got = ea.render(a, gs, out_n)
+        ref = jobs.oracle_render(a, os_, nch=out_n)
+        same = bits(got) == bits(ref)
+        assert same.all(), f"{what}: {int((~same).sum())} of {same.size} words differ"
+        for g in gs:
+            g.release()
