@@ -322,7 +322,7 @@ __device__ __forceinline__ eu_f2 eu_gate2_ok(eu_f2 c, int kind, float lower, flo
   return cc + lower;
 }
 
-template <int PRJ>
+template <int PRJ, bool FAST = false>
 __device__ __forceinline__ eu_i2 eu_coord2_ok(const eu_src_dev &s, const eu_ray2 &r, eu_f2 &sx,
                                               eu_f2 &sy, const float *atab, eu_i2 &ok)
 {
@@ -375,11 +375,11 @@ __device__ __forceinline__ eu_i2 eu_coord2_ok(const eu_src_dev &s, const eu_ray2
     eu_f2 lat = eu_atan2f_2_tab_ok(r.y, qs, atab, 1, ok);
     eu_f2 lon = eu_atan2f_2_tab_ok(r.x, r.z, atab, 0, ok);
     eu_i2 hit = { -1, -1 };
-    if (!s.always_hit)
+    if (!FAST && !s.always_hit)
       hit = (lon >= s.wex0) & (lon <= s.wex1) & (lat >= s.wex2) & (lat <= s.wex3);
     eu_f2 i0 = { (float)((double)lon.x - s.tex_x0), (float)((double)lon.y - s.tex_x0) };
     eu_f2 i1 = { (float)((double)lat.x - s.tex_y0), (float)((double)lat.y - s.tex_y0) };
-    if (s.cdiv_ok) {
+    if (FAST || s.cdiv_ok) {
       i0 = eu_div2_const(i0, s.ext_w, s.rcp_ext_w);
       i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
     } else {

@@ -32,6 +32,7 @@
 // Stands in for: zimt::process' get/act/put loop (wielding.h:151-463) with the
 // evaluator's gathers (zimt/eval.h:838-889) replaced by LDS reads.
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 #include <algorithm>
@@ -327,7 +328,7 @@ __device__ __forceinline__ void eu4_tile(const eu_render_params &p, const eu4_pl
     // ~88 returning atomics per microsecond on one word)
     if (lane == 0) {
       const int id = tile_y * w.tiles16 + x0 / EU4_TW;
-      const int sh = id & (EU4_SHARDS - 1);
+      const int sh = (int)(((unsigned)id * 0x9E3779B1u) >> 22) & (EU4_SHARDS - 1);   // eu4_shard_of
       const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
       p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
     }
@@ -437,6 +438,378 @@ __global__ __launch_bounds__(64 * EU4_WAVES0, EU4_OCC0) void eu_render4s_kernel(
                                                   tile_y, tile_x * EU4_TW, lane);
   else
     eu4_tile<NCH, DEG, PRJ, false>(p, w, atab, tile, nullptr, tile_y, tile_x * EU4_TW, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Round 3: the staged kernel as PERSISTENT wavefronts (eu_render5_kernel).
+//
+// What round 2's measurements said about eu_render4s_kernel: with the L1 traffic
+// gone a wave lives ~11k cycles of which it issues vector instructions for ~2.5k, and the 16
+// single-wave workgroups a CU admits leave four such waves per SIMD; 17 % of the headline's tiles
+// (the polar faces' wide boxes) fall to the direct-gather kernel, which takes 0.63 ms for them.
+// This kernel keeps the staging and changes what surrounds it:
+//   * workgroups of four independent waves stay resident for the whole launch and walk the
+//     tiles of their XCD in raster order (wave k of the XCD takes tiles k, k + K, ...): no
+//     wave launch, no atanf table load and no LDS allocation per tile; five waves per SIMD
+//     (96 registers, 7 KB of LDS per wave + one table per workgroup),
+//   * lane -> pixel mapping [half | row | pair]: lanes 0-31 are the left 8x8 half of the 16x8
+//     tile, DPP rows of 16 lanes are 8x4 quarters, so ONE reduction yields the boxes of the
+//     quarters, the halves and the tile. A tile whose box exceeds the slice is staged and
+//     evaluated as two halves or four quarters, one after the other in the same slice
+//     (the polar faces of the headline: 60 % of the tiles in one pass, 28 % in two, 8 % in
+//     four; 4.7 % - the pole itself - remain for the work list),
+//   * the weighted sum written on register PAIRS: ds_read_b128 returns (R,G),(B,X); the
+//     x weights of the lane's two pixels sit in one pair and are broadcast with op_sel, so
+//     a window row is 14 packed operations per pixel (zimt/eval.h:904-1059: same products,
+//     same order of additions, per channel).
+// ---------------------------------------------------------------------------
+#define EU5_WAVES 4
+#ifndef EU5_TEXELS
+#define EU5_TEXELS 448      // LDS texels (16 bytes) per wave: 4 x 7 KB + 3 KB table = 31 KB per workgroup, 5 per CU
+#endif
+#ifndef EU5_OCC
+#define EU5_OCC 5           // waves per SIMD the registers are capped for
+#endif
+#ifndef EU5_UNIT_ROWS
+#define EU5_UNIT_ROWS 4     // tile rows per XCD unit
+#endif
+
+// the work list a tile goes to: a multiplicative hash of the tile id. (id % EU4_SHARDS keeps the
+// tile COLUMN: the tiles around a pole then land in a sixth of the lists, and the direct-gather
+// kernel's waves on those lists work through ~10 tiles each while the others idle: 0.23 ms for
+// 1.6 % of the headline's tiles.)
+__device__ __forceinline__ int eu4_shard_of(int id)
+{
+  return (int)(((unsigned)id * 0x9E3779B1u) >> 22) & (EU4_SHARDS - 1);
+}
+
+typedef const __attribute__((address_space(3))) eu4_f4 *eu5_l4ptr;
+
+// the (d+1)^2 taps of both pixels from the LDS image; a, b: float offsets of the two windows
+// inside the wave's slice, pitch in floats. wx[i] / wy[j] = (weight of pixel a, weight of pixel b).
+// Results: (R,G) and (B,X) of pixel a and of pixel b.
+template <int NCH, int DEG>
+__device__ __forceinline__ void eu5_taps(eu_lptr lt, int a, int b, int pitch, const eu_f2 *wx, const eu_f2 *wy,
+                                         eu_f2 tx, eu_f2 ty, eu_f2 &rga, eu_f2 &bxa, eu_f2 &rgb, eu_f2 &bxb)
+{
+  constexpr int order = DEG + 1;
+  if constexpr (DEG == 1) {
+    // _eval_linear, eval.h:1014-1059: wl = 1 - t, wr = t
+    const eu_f2 wl0 = 1.0f - tx, wr0 = tx, wl1 = 1.0f - ty, wr1 = ty;
+    const eu4_f4 a00 = *(eu5_l4ptr)(lt + a), a01 = *(eu5_l4ptr)(lt + a + 4);
+    const eu4_f4 a10 = *(eu5_l4ptr)(lt + a + pitch), a11 = *(eu5_l4ptr)(lt + a + pitch + 4);
+    const eu4_f4 b00 = *(eu5_l4ptr)(lt + b), b01 = *(eu5_l4ptr)(lt + b + 4);
+    const eu4_f4 b10 = *(eu5_l4ptr)(lt + b + pitch), b11 = *(eu5_l4ptr)(lt + b + pitch + 4);
+    {
+      const eu_f2 l0 = { wl0.x, wl0.x }, r0 = { wr0.x, wr0.x }, l1 = { wl1.x, wl1.x }, r1 = { wr1.x, wr1.x };
+      eu_f2 s = a00.xy * l0; s = s + a01.xy * r0; s = s * l1;
+      eu_f2 u = a10.xy * l0; u = u + a11.xy * r0; rga = s + u * r1;
+      s = a00.zw * l0; s = s + a01.zw * r0; s = s * l1;
+      u = a10.zw * l0; u = u + a11.zw * r0; bxa = s + u * r1;
+    }
+    {
+      const eu_f2 l0 = { wl0.y, wl0.y }, r0 = { wr0.y, wr0.y }, l1 = { wl1.y, wl1.y }, r1 = { wr1.y, wr1.y };
+      eu_f2 s = b00.xy * l0; s = s + b01.xy * r0; s = s * l1;
+      eu_f2 u = b10.xy * l0; u = u + b11.xy * r0; rgb = s + u * r1;
+      s = b00.zw * l0; s = s + b01.zw * r0; s = s * l1;
+      u = b10.zw * l0; u = u + b11.zw * r0; bxb = s + u * r1;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < order; j++) {
+      eu4_f4 ta[order], tb[order];
+#pragma unroll
+      for (int i = 0; i < order; i++) {
+        ta[i] = *(eu5_l4ptr)(lt + a + j * pitch + 4 * i);
+        tb[i] = *(eu5_l4ptr)(lt + b + j * pitch + 4 * i);
+      }
+      const eu_f2 w0a = { wx[0].x, wx[0].x }, w0b = { wx[0].y, wx[0].y };
+      eu_f2 ra = ta[0].xy * w0a, qa = ta[0].zw * w0a, rb = tb[0].xy * w0b, qb = tb[0].zw * w0b;
+#pragma unroll
+      for (int i = 1; i < order; i++) {
+        const eu_f2 wa = { wx[i].x, wx[i].x }, wb = { wx[i].y, wx[i].y };
+        ra = ra + wa * ta[i].xy; qa = qa + wa * ta[i].zw;
+        rb = rb + wb * tb[i].xy; qb = qb + wb * tb[i].zw;
+      }
+      const eu_f2 ya = { wy[j].x, wy[j].x }, yb = { wy[j].y, wy[j].y };
+      if (j == 0) { rga = ra * ya; bxa = qa * ya; rgb = rb * yb; bxb = qb * yb; }
+      else { rga = rga + ra * ya; bxa = bxa + qa * ya; rgb = rgb + rb * yb; bxb = bxb + qb * yb; }
+    }
+  }
+}
+
+// Bounding boxes by one DPP reduction: log-step row shifts inside the rows of 16 lanes (lane 15
+// of every row then holds its quarter's box), then the row broadcast into COPIES (lanes 31 and
+// 63 of the copies hold the boxes of the halves; the quarters stay readable). Four reductions
+// interleaved: three independent instructions between dependent DPP operations.
+__device__ __forceinline__ void eu5_box_reduce(int &q0, int &q1, int &q2, int &q3, int &h0, int &h1, int &h2, int &h3)
+{
+#define EU5_RED(ctrl)                                        \
+  "v_min_i32_dpp %0, %0, %0 " ctrl "\n\t"                    \
+  "v_min_i32_dpp %1, %1, %1 " ctrl "\n\t"                    \
+  "v_max_i32_dpp %2, %2, %2 " ctrl "\n\t"                    \
+  "v_max_i32_dpp %3, %3, %3 " ctrl "\n\t"
+  asm("s_nop 1\n\t"
+      EU5_RED("row_shr:1 row_mask:0xf bank_mask:0xf")
+      EU5_RED("row_shr:2 row_mask:0xf bank_mask:0xf")
+      EU5_RED("row_shr:4 row_mask:0xf bank_mask:0xf")
+      EU5_RED("row_shr:8 row_mask:0xf bank_mask:0xf")
+      "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+      "v_min_i32_dpp %4, %0, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_min_i32_dpp %5, %1, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_i32_dpp %6, %2, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_i32_dpp %7, %3, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3));
+#undef EU5_RED
+}
+
+struct eu5_box { int mnx, mny, mxx, mxy; };
+
+__device__ __forceinline__ eu5_box eu5_box_at(int a, int b, int c, int d, int lane)
+{
+  eu5_box r;
+  r.mnx = __builtin_amdgcn_readlane(a, lane); r.mny = __builtin_amdgcn_readlane(b, lane);
+  r.mxx = __builtin_amdgcn_readlane(c, lane); r.mxy = __builtin_amdgcn_readlane(d, lane);
+  return r;
+}
+__device__ __forceinline__ eu5_box eu5_box_join(const eu5_box &a, const eu5_box &b)
+{
+  eu5_box r = { min(a.mnx, b.mnx), min(a.mny, b.mny), max(a.mxx, b.mxx), max(a.mxy, b.mxy) };
+  return r;
+}
+// 1: fits the slice, 0: does not, -1: empty (no hitting pixel)
+template <int ORDER>
+__device__ __forceinline__ int eu5_box_fits(const eu5_box &b)
+{
+  if (b.mnx == INT_MAX) return -1;
+  const long long bw = (long long)b.mxx - b.mnx + ORDER, bh = (long long)b.mxy - b.mny + ORDER;
+  return bw <= 64 && bh <= EU5_TEXELS && bw * bh <= EU5_TEXELS;
+}
+
+// FAST: the job's uniform switches as compile-time constants - 'ray = B * c0 + A' without
+// normalisation, no bands, every ray hits, the verified constant division, brighten 1 (what a
+// cubemap / rectilinear target of a full-sphere or cubemap source is). The persistent loop keeps
+// every scalar it uses live: fewer of them means no SGPR spills in the tile code.
+template <int NCH, int DEG, int PRJ, bool HOIST, bool FAST>
+__device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_plan &w, const float *atab,
+                                         float *wtile, const float *ct, int tile_y, int x0, int lane)
+{
+  constexpr int TEX = 4;
+  constexpr int order = DEG + 1;
+  const eu_src_dev &s = p.src;
+  const int pr = lane & 3, rw = (lane >> 2) & 7, hf = lane >> 5;
+  const int y = p.row_begin + tile_y * EU4_TH + rw;
+  const bool yin = y < p.row_end;
+  const int yc = yin ? y : p.row_end - 1;
+  const float *rt = p.row + (long long)(FAST ? yc : eu_frame_row(yc, p.band_shift, p.band_count, p.band_index)) * EU_ROW_FLOATS;
+  const int xa = x0 + 8 * hf + 2 * pr, xb = xa + 1;
+  const bool va = yin && xa < p.width, vb = yin && xb < p.width;
+  const int xac = xa < p.width ? xa : p.width - 1, xbc = xb < p.width ? xb : p.width - 1;
+
+  eu_f2 tx, ty, gy;
+  eu_i2 hit, ok = { -1, -1 };
+  int ixa, ixb;
+  eu_f2 wx[order], wy[order];
+  if constexpr (HOIST) {
+    const float4 *ea = (const float4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
+    const float4 *eb = (const float4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
+    const float4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
+    const float A1 = rt[1], B1 = rt[4];
+    const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+    const eu_f2 ryy = B1 * c0 + A1;
+    ixa = __float_as_int(a0.x); ixb = __float_as_int(b0.x);
+    ok = ok & (eu_i2){ ixa != INT_MIN ? -1 : 0, ixb != INT_MIN ? -1 : 0 };
+    tx = (eu_f2){ a0.y, b0.y };
+    if constexpr (DEG >= 2) {
+      wx[0] = (eu_f2){ a0.z, b0.z }; wx[1] = (eu_f2){ a0.w, b0.w }; wx[2] = (eu_f2){ a1.x, b1.x };
+      if constexpr (DEG == 3) wx[3] = (eu_f2){ a1.y, b1.y };
+    }
+    const eu_f2 qs = { a1.z, b1.z };
+    const eu_f2 lat = eu_atan2f_2_tab_ok(ryy, qs, atab, 1, ok);
+    hit = (eu_i2){ -1, -1 };
+    if (!FAST && !s.always_hit) {
+      const eu_f2 lon = { a1.w, b1.w };
+      hit = (lon >= s.wex0) & (lon <= s.wex1) & (lat >= s.wex2) & (lat <= s.wex3);
+    }
+    eu_f2 i1 = { (float)((double)lat.x - s.tex_y0), (float)((double)lat.y - s.tex_y0) };
+    if (FAST || s.cdiv_ok) i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
+    else i1 = i1 / s.ext_h;
+    i1 = i1 * s.total_h; i1 = i1 - .5f;
+    const eu_f2 sy = i1 - s.win_y_off;
+    gy = eu_gate2_ok(sy, s.gate1, s.lower1, s.upper1, ok);
+  } else {
+    eu_ray2 r;
+    {
+      const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
+      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      if (!FAST && p.form == EU_FORM_BCA) {
+        const float C0 = rt[6], C1 = rt[7], C2 = rt[8];
+        const float *colB = p.col + p.width;
+        const eu_f2 c1 = { colB[xac], colB[xbc] };
+        r.x = B0 * c0 + C0 * c1 + A0;
+        r.y = B1 * c0 + C1 * c1 + A1;
+        r.z = B2 * c0 + C2 * c1 + A2;
+      } else {
+        r.x = B0 * c0 + A0;
+        r.y = B1 * c0 + A1;
+        r.z = B2 * c0 + A2;
+      }
+      if (!FAST && p.norm_mode == EU_NORM_DIV) {
+        eu_f2 sqn = r.x * r.x; sqn = sqn + r.y * r.y; sqn = sqn + r.z * r.z;
+        const eu_f2 n = { sqrtf(sqn.x), sqrtf(sqn.y) };
+        r.x = r.x / n; r.y = r.y / n; r.z = r.z / n;
+      }
+    }
+    eu_f2 sx, sy;
+    hit = eu_coord2_ok<PRJ, FAST>(s, r, sx, sy, atab, ok);
+    const eu_f2 gx = eu_gate2_ok(sx, s.gate0, s.lower0, s.upper0, ok);
+    gy = eu_gate2_ok(sy, s.gate1, s.lower1, s.upper1, ok);
+    eu_f2 fx;
+    if constexpr (DEG & 1) fx = (eu_f2){ floorf(gx.x), floorf(gx.y) };
+    else fx = (eu_f2){ roundf(gx.x), roundf(gx.y) };
+    tx = gx - fx;
+    ixa = (int)fx.x; ixb = (int)fx.y;
+  }
+  hit = hit & (eu_i2){ va ? -1 : 0, vb ? -1 : 0 };
+  eu_f2 fy;
+  if constexpr (DEG & 1) fy = (eu_f2){ floorf(gy.x), floorf(gy.y) };
+  else fy = (eu_f2){ roundf(gy.x), roundf(gy.y) };
+  ty = gy - fy;
+  const int iya = (int)fy.x, iyb = (int)fy.y;
+
+  // boxes of the base positions of the hitting pixels: quarters (q*, lane 15 of every row of 16
+  // lanes), halves (h*, lanes 31 and 63), tile
+  int q0 = INT_MAX, q1 = INT_MAX, q2 = INT_MIN, q3 = INT_MIN, h0, h1, h2, h3;
+  if (hit.x) { q0 = ixa; q2 = ixa; q1 = iya; q3 = iya; }
+  if (hit.y) { q0 = min(q0, ixb); q2 = max(q2, ixb); q1 = min(q1, iyb); q3 = max(q3, iyb); }
+  eu5_box_reduce(q0, q1, q2, q3, h0, h1, h2, h3);
+  const eu5_box full = eu5_box_join(eu5_box_at(h0, h1, h2, h3, 31), eu5_box_at(h0, h1, h2, h3, 63));
+  const bool clean = __ballot((hit.x && !ok.x) || (hit.y && !ok.y)) == 0ull;
+  // passes: the tile at once, its halves or its quarters, whichever fits the slice first
+  int npass = 1;
+  const int f = eu5_box_fits<order>(full);
+  if (f < 0) npass = 0;                               // nothing hits: zeros
+  else if (f == 0) {
+    npass = 2;
+    if (eu5_box_fits<order>(eu5_box_at(h0, h1, h2, h3, 31)) == 0 || eu5_box_fits<order>(eu5_box_at(h0, h1, h2, h3, 63)) == 0) {
+      npass = 4;
+      if (eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 15)) == 0 || eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 31)) == 0 ||
+          eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 47)) == 0 || eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 63)) == 0)
+        npass = -1;
+    }
+  }
+  float *const orow = p.out + (long long)(yc - p.row_begin) * p.out_stride;
+  if (npass < 0 || (npass > 0 && !clean)) {
+    // not even the quarters fit (the pole of a lat/lon source, the +-180 degree seam, strong
+    // minification), or a hitting pixel left the fast path of the coordinate arithmetic: left to the
+    // direct-gather kernel behind this one
+    if (lane == 0) {
+      const int id = tile_y * w.tiles16 + x0 / EU4_TW;
+      const int sh = eu4_shard_of(id);
+      const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
+      p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
+    }
+    return;
+  }
+  eu_f2 rga = { 0.0f, 0.0f }, bxa = { 0.0f, 0.0f }, rgb = { 0.0f, 0.0f }, bxb = { 0.0f, 0.0f };
+  if (npass > 0) {
+    if constexpr (DEG >= 2) {
+      eu_weights2<DEG>(s.wm, ty, wy);
+      if constexpr (!HOIST) eu_weights2<DEG>(s.wm, tx, wx);
+    }
+    const unsigned lds_tile = (unsigned)(unsigned long long)(eu4_lds_void)wtile;
+    const int grp = npass == 1 ? 0 : npass == 2 ? hf : (lane >> 4);
+#pragma unroll 1
+    for (int pi = 0; pi < npass; pi++) {
+      eu5_box bx = full;
+      if (npass > 1) {
+        // lane 31 / 63 of the halves' copies, lane 15 / 31 / 47 / 63 of the quarters
+        const int ln = npass == 2 ? 31 + 32 * pi : 15 + 16 * pi;
+        const eu5_box bh = eu5_box_at(h0, h1, h2, h3, ln), bq = eu5_box_at(q0, q1, q2, q3, ln);
+        bx = npass == 2 ? bh : bq;
+      }
+      if (bx.mnx == INT_MAX) continue;               // a half / quarter without a hitting pixel
+      const int ibw = bx.mxx - bx.mnx + order, ibh = bx.mxy - bx.mny + order;
+      if (lane < ibw) {
+        const int bx0 = bx.mnx - DEG / 2, by0 = bx.mny - DEG / 2;
+        const unsigned voff = (unsigned)(lane * NCH) * 4u;
+        const char *sb = (const char *)(s.base + ((long long)by0 * s.es1 + (long long)bx0 * NCH));
+        const long long step = s.es1 * 4;
+        unsigned dst = lds_tile;
+        const unsigned dstep = (unsigned)ibw * (TEX * 4u);
+#pragma unroll 1
+        for (int it = 0; it < ibh; it++) { eu4_dma_row(dst, voff, sb); sb += step; dst += dstep; }
+      }
+      // lanes of other groups and lanes without a hit read the box origin
+      const bool mine = grp == pi;
+      const int oa = (mine && hit.x) ? ((iya - bx.mny) * ibw + (ixa - bx.mnx)) * TEX : 0;
+      const int ob = (mine && hit.y) ? ((iyb - bx.mny) * ibw + (ixb - bx.mnx)) * TEX : 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (mine) eu5_taps<NCH, DEG>((eu_lptr)wtile, oa, ob, ibw * TEX, wx, wy, tx, ty, rga, bxa, rgb, bxb);
+    }
+  }
+  // environment::eval brighten (environment.h:1821-1842), zero on a miss; storer
+  float qa[4] = { rga.x, rga.y, bxa.x, bxa.y }, qb[4] = { rgb.x, rgb.y, bxb.x, bxb.y };
+  constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
+  const bool bright = !FAST && s.brighten != 1.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    float a = qa[c], bb = qb[c];
+    if (bright && c < ncol) { a = a * s.brighten; bb = bb * s.brighten; }
+    qa[c] = hit.x ? a : 0.0f;
+    qb[c] = hit.y ? bb : 0.0f;
+  }
+  if (va) eu_put<NCH>(orow, xa, qa);
+  if (vb) eu_put<NCH>(orow, xb, qb);
+}
+
+// grid: 8 * (workgroups per XCD); the launcher sizes it to what is resident at once
+template <int NCH, int DEG, int PRJ, bool FAST>
+__global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(const eu_render_params p, const eu4_plan w)
+{
+  __shared__ __attribute__((aligned(16))) float tile_all[EU5_WAVES * EU5_TEXELS * 4];
+  __shared__ __attribute__((aligned(16))) float atab[768];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *const tile = tile_all + wave * (EU5_TEXELS * 4);
+  if (PRJ != EU_CUBEMAP && wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      __builtin_amdgcn_global_load_lds((eu4_gbl_void)(w.atab_g + i * 256 + lane * 4),
+                                       (eu4_lds_void)(atab + i * 256), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // blocks are dealt round-robin to the 8 XCDs: blockIdx.x & 7 names the XCD (up to a rotation;
+  // for speed only). XCD x owns the units x, x + 8, ... of EU5_UNIT_ROWS tile rows; its waves
+  // walk that list in raster order, wave k taking tiles k, k + K, ...
+  const int xcd = (int)(blockIdx.x & 7);
+  const int K = (int)(gridDim.x >> 3) * EU5_WAVES;
+  const int per_unit = EU5_UNIT_ROWS * w.tiles16;
+  const int units = (p.tiles_y + EU5_UNIT_ROWS - 1) / EU5_UNIT_ROWS;
+  const int t0 = (int)(blockIdx.x >> 3) * EU5_WAVES + wave;
+  int ul = t0 / per_unit;
+  int ry = (t0 - ul * per_unit) / w.tiles16;
+  int rx = t0 - ul * per_unit - ry * w.tiles16;
+  const int du = K / per_unit, dy = (K - du * per_unit) / w.tiles16, dx = K - du * per_unit - dy * w.tiles16;
+#pragma unroll 1
+  while (true) {
+    const int unit = ul * 8 + xcd;
+    if (unit >= units) break;
+    const int tile_y = unit * EU5_UNIT_ROWS + ry;
+    if (tile_y < p.tiles_y) {
+      const int plan = PRJ == EU_SPHERICAL ? w.tileplan[tile_y] : -1;
+      if (plan >= 0)
+        eu5_tile<NCH, DEG, PRJ, PRJ == EU_SPHERICAL, FAST>(p, w, atab, tile, w.coltab + (size_t)plan * p.width * EU4_COL_FLOATS,
+                                                            tile_y, rx * EU4_TW, lane);
+      else
+        eu5_tile<NCH, DEG, PRJ, false, FAST>(p, w, atab, tile, nullptr, tile_y, rx * EU4_TW, lane);
+    }
+    rx += dx; ry += dy; ul += du;
+    if (rx >= w.tiles16) { rx -= w.tiles16; ry++; }
+    if (ry >= EU5_UNIT_ROWS) { ry -= EU5_UNIT_ROWS; ul++; }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -573,9 +946,40 @@ __global__ __launch_bounds__(256, 4) void eu_render4d_kernel(const eu_render_par
 template <int NCH, int DEG, int PRJ>
 static int launch4_ndp(const eu_render_params &p, const eu4_plan &w, hipStream_t st)
 {
-  const int units = (p.tiles_y + EU4_UNIT_ROWS - 1) / EU4_UNIT_ROWS;
-  dim3 grid((unsigned)(8 * ((w.tiles16 + EU4_WAVES0 - 1) / EU4_WAVES0)), (unsigned)EU4_UNIT_ROWS, (unsigned)((units + 7) / 8));
-  hipLaunchKernelGGL((eu_render4s_kernel<NCH, DEG, PRJ>), grid, dim3(64 * EU4_WAVES0), 0, st, p, w);
+  // EU_HIP_R5: 1 (default) the persistent staged kernel of round 3, 0 round 2's one-tile-per-workgroup form
+  const char *r5env = getenv("EU_HIP_R5");
+  if (!(r5env && r5env[0] == '0')) {
+    // as many workgroups as are resident at once (a persistent kernel must not queue a second round)
+    static const int per_cu_env = [] { const char *e = getenv("EU_HIP_R5_WGS"); return e ? atoi(e) : 0; }();   // A/B runs
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess) return 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+      return n;
+    }();
+    const bool fast = p.form == EU_FORM_BA && p.norm_mode == EU_NORM_NONE && p.band_count <= 1 && p.src.brighten == 1.0f &&
+                      (p.src.prj != EU_SPHERICAL || (p.src.always_hit && p.src.cdiv_ok));
+    static const bool dbg = getenv("EU_HIP_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "eu_render5: fast %d (form %d norm %d bands %d brighten %g always_hit %d cdiv_ok %d)\n", (int)fast, p.form,
+                     p.norm_mode, p.band_count, (double)p.src.brighten, p.src.always_hit, p.src.cdiv_ok);
+    int per_cu = 0;
+    if (fast) {
+      static const int occ = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, eu_render5_kernel<NCH, DEG, PRJ, true>, 64 * EU5_WAVES, 0) == hipSuccess ? n : 0; }();
+      per_cu = occ;
+    } else {
+      static const int occ = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, eu_render5_kernel<NCH, DEG, PRJ, false>, 64 * EU5_WAVES, 0) == hipSuccess ? n : 0; }();
+      per_cu = occ;
+    }
+    if (per_cu_env > 0) per_cu = std::min(per_cu, per_cu_env);
+    const int wgs = (cus / 8) * 8 * per_cu;
+    if (wgs <= 0) return -1;
+    if (fast) hipLaunchKernelGGL((eu_render5_kernel<NCH, DEG, PRJ, true>), dim3((unsigned)wgs), dim3(64 * EU5_WAVES), 0, st, p, w);
+    else hipLaunchKernelGGL((eu_render5_kernel<NCH, DEG, PRJ, false>), dim3((unsigned)wgs), dim3(64 * EU5_WAVES), 0, st, p, w);
+  } else {
+    const int units = (p.tiles_y + EU4_UNIT_ROWS - 1) / EU4_UNIT_ROWS;
+    dim3 grid((unsigned)(8 * ((w.tiles16 + EU4_WAVES0 - 1) / EU4_WAVES0)), (unsigned)EU4_UNIT_ROWS, (unsigned)((units + 7) / 8));
+    hipLaunchKernelGGL((eu_render4s_kernel<NCH, DEG, PRJ>), grid, dim3(64 * EU4_WAVES0), 0, st, p, w);
+  }
   if (hipGetLastError() != hipSuccess) return -1;
   hipLaunchKernelGGL((eu_render4d_kernel<NCH, DEG, PRJ>), dim3(EU4_DIRECT_WGS), dim3(256), 0, st, p, w);
   return hipGetLastError() == hipSuccess ? 0 : -1;
