@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <vector>
 #include <new>
@@ -69,6 +70,7 @@ struct context {
   std::vector<unsigned char> seg_flags;
   bool seg_valid = false, seg_mixed = false;
   unsigned long long plan_gen = 0;                // bumped whenever the stepper tables change
+  int tab_finite = 0;                             // every entry of the plan's stepper tables is finite
   unsigned long long launches = 0;                // render kernel launches so far
   eu_src_dev seg_sd;
   float *stage = nullptr; size_t stage_cap = 0;   // host-output staging
@@ -442,8 +444,12 @@ int build_params(const eu_target *t, eu_source *const *srcs, int nsrc, float *ou
     g.h_row.swap(tb.row);
     g.seg_valid = false;
     g.plan_gen++;
+    g.tab_finite = 1;
+    for (float v : g.h_col) if (!std::isfinite(v)) g.tab_finite = 0;
+    for (float v : g.h_row) if (!std::isfinite(v)) g.tab_finite = 0;
   }
   memset(p, 0, sizeof *p);
+  p->tab_finite = g.tab_finite;
   p->width = frame_w(t); p->height = frame_h(t);
   p->row_begin = t->row_begin; p->row_end = t->row_end;
   if (t->band_count > 1) {

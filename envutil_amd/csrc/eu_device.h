@@ -113,6 +113,8 @@ struct eu_render_params {
                              // the tiles left to the direct-gather kernel (layout: EU4_WL_*)
   int layout;                // packed kernel: 0 by environment (default row strips), 1 row strips,
                              // 2 32x16 tiles with direct gathers (eu_render2.hip)
+  int tab_finite;            // every entry of the stepper tables is finite (checked on the host when the
+                             // plan is built): rays are then finite or +-inf, never NaN (eu_render5's range test)
   eu_src_dev src;
   eu_generic gen;            // form == EU_FORM_GENERIC
   eu_inv_planar inv;         // ... of a --single job (all zero otherwise)

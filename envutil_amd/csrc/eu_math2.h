@@ -314,7 +314,91 @@ EU_D2 eu_f2 eu_sqrt2_ok(eu_f2 x, eu_i2 &ok)
   return eu_sqrt2_safe(x);
 }
 
+// ---------------------------------------------------------------------------
+// Round 3: the same functions with fewer vector instructions (eu_render5_kernel's FAST profile).
+// Same operations on the same operands as eu_atanf_pos2_tab / eu_atan2f_2_tab_ok - only the
+// instruction forms differ:
+//   * the per-pixel table fields feed SCALAR operations (any register will do; as operands of
+//     packed operations they first had to be moved into pairs: 12 v_mov per atanf),
+//   * num = a * t + b with a in {0, 1, 2} is ONE fma (a * t is exact, so RN(a * t + b) is the
+//     reference's RN(RN(a * t) + b)); den = RN(RN(c * t) + d) stays two operations (c = 1.5),
+//   * the |t| < 7/16 row of the table has hi = lo = 0: hi - ((xs - lo) - x) = 0 - (xs - x) is
+//     x - xs bit for bit, so no select,
+//   * t >= 2^25 (the reference returns atanhi[3] + atanlo[3]) is reported in `big` instead of
+//     being selected: the caller hands such a tile to the kernel with the fallbacks.
+// ---------------------------------------------------------------------------
+// atanf(|q|) for both lanes; big.x / big.y: |q| >= 2^25 (the result of that lane is not valid)
+EU_D2 eu_f2 eu_atanf_abs2_lean(eu_f2 q, const float *tab, eu_i2 &big)
+{
+  const eu_u2 iq = eu_bits2(q);
+  const unsigned k0 = (iq.x >> 18) & 0x1fffu, k1 = (iq.y >> 18) & 0x1fffu;   // v_bfe_u32: sign excluded
+  big = (eu_i2){ k0 >= 0x1300u ? -1 : 0, k1 >= 0x1300u ? -1 : 0 };           // 0x4c000000 >> 18
+  const unsigned j0 = (k0 < 0xfb7u ? 0xfb7u : k0 > 0x1007u ? 0x1007u : k0) - 0xfb7u;
+  const unsigned j1 = (k1 < 0xfb7u ? 0xfb7u : k1 > 0x1007u ? 0x1007u : k1) - 0xfb7u;
+  const float *e0 = tab + j0 * 8, *e1 = tab + j1 * 8;
+  const float a0 = e0[0], b0 = e0[1], c0 = e0[2], h0 = e0[4], l0 = e0[5];
+  const float a1 = e1[0], b1 = e1[1], c1 = e1[2], h1 = e1[4], l1 = e1[5];
+  const float t0 = __builtin_fabsf(q.x), t1 = __builtin_fabsf(q.y);
+  const eu_f2 num = { __builtin_fmaf(a0, t0, b0), __builtin_fmaf(a1, t1, b1) };
+  float d0 = c0 * t0, d1 = c1 * t1;
+  d0 = d0 + a0; d1 = d1 + a1;                 // d == a in every row of the table
+  const eu_f2 den = { d0, d1 };
+  const eu_f2 x = eu_div2_safe(num, den);
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+              aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+              aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+              aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+  const eu_f2 z = x * x;
+  const eu_f2 w = z * z;
+  const eu_f2 s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  const eu_f2 s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  const eu_f2 xs = x * (s1 + s2);
+  eu_f2 u = { xs.x - l0, xs.y - l1 };
+  u = u - x;
+  return (eu_f2){ h0 - u.x, h1 - u.y };
+}
+
+// atan2f(y, x), operands in range (the caller checks), x > 0 when x_positive
+EU_D2 eu_f2 eu_atan2f_2_lean(eu_f2 y, eu_f2 x, const float *tab, int x_positive, eu_i2 &big)
+{
+  const eu_f2 q = eu_div2_safe(y, x);
+  const eu_f2 z = eu_atanf_abs2_lean(q, tab, big);
+  const eu_u2 hy = eu_bits2(y);
+  eu_f2 m = z;
+  if (!x_positive) {
+    // m = 0 / 1: +-z; m = 2 / 3: +-(pi - (z - pi_lo))   (zl - pi = -(pi - zl) exactly)
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const eu_f2 zl = z - pi_lo;
+    const eu_f2 t = pi - zl;
+    const eu_i2 xneg = (eu_i2)eu_bits2(x) < 0;
+    m = eu_sel2(xneg, t, z);
+  }
+  // z >= +0 and t > 0: the result is m with y's sign bit
+  return eu_float2((eu_bits2(m) & 0x7fffffffu) | (hy & 0x80000000u));
+}
+
+// x / c with r = the refined reciprocal of c as LLVM's division computes it (eu_rcp_refined):
+// the rest of eu_div2_safe's sequence, i.e. the correctly rounded quotient for x in {0} u
+// [2^-90, 2^90] and c in [2^-90, 2^90]
+EU_D2 eu_f2 eu_div2_rr(eu_f2 x, float c, float r)
+{
+  const eu_f2 cc = { c, c }, rr = { r, r };
+  eu_f2 q = x * rr;
+  eu_f2 e = eu_fma2(-cc, q, x);
+  q = eu_fma2(e, rr, q);
+  e = eu_fma2(-cc, q, x);
+  return eu_fma2(e, rr, q);
+}
+
 #if defined(__HIPCC__)
+// the reciprocal eu_div2_safe forms from v_rcp_f32 before it multiplies (device only)
+__device__ __forceinline__ float eu_rcp_refined(float d)
+{
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+
 // n / d: range-checked FMA division (eu_div2_safe), hipcc's correctly rounded
 // `/` for the lanes outside the range - the same bits either way
 __device__ __forceinline__ eu_f2 eu_div2_guarded(eu_f2 n, eu_f2 d)

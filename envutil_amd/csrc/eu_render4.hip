@@ -205,7 +205,16 @@ struct eu4_plan {
   const int *tileplan;    // per tile row of the launch: column table to use, -1: none
   const float *coltab;    // [plan][width][EU4_COL_FLOATS]
   int tiles16;            // wave tiles per tile row
+#ifdef EU5_STAMPS
+  unsigned long long *stamps;   // diagnostic build: 8 s_memtime stamps per tile of eu_render5_kernel
+#endif
 };
+
+#ifdef EU5_STAMPS
+#define EU5_STAMP(k) do { asm volatile("" ::: "memory"); st_[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define EU5_STAMP(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // one tile of the staged kernel. HOIST: the x half of the coordinate chain comes from the
@@ -566,6 +575,18 @@ __device__ __forceinline__ void eu5_box_reduce(int &q0, int &q1, int &q2, int &q
 
 struct eu5_box { int mnx, mny, mxx, mxy; };
 
+// for a box width w (1..64): ceil(2^16 / w) in the low 17 bits - (lane * M) >> 16 is lane / w for every
+// lane < 64 - and 64 / w, the rows one LDS-DMA instruction covers, in the top byte
+struct eu5_divtab_t { unsigned v[65]; };
+static constexpr eu5_divtab_t eu5_make_divtab()
+{
+  eu5_divtab_t t = {};
+  t.v[0] = 0;
+  for (unsigned w = 1; w <= 64; w++) t.v[w] = ((65536u + w - 1) / w) | ((64u / w) << 24);
+  return t;
+}
+__constant__ const eu5_divtab_t eu5_divtab = eu5_make_divtab();
+
 __device__ __forceinline__ eu5_box eu5_box_at(int a, int b, int c, int d, int lane)
 {
   eu5_box r;
@@ -583,8 +604,34 @@ template <int ORDER>
 __device__ __forceinline__ int eu5_box_fits(const eu5_box &b)
 {
   if (b.mnx == INT_MAX) return -1;
-  const long long bw = (long long)b.mxx - b.mnx + ORDER, bh = (long long)b.mxy - b.mny + ORDER;
-  return bw <= 64 && bh <= EU5_TEXELS && bw * bh <= EU5_TEXELS;
+  // 32-bit scalar arithmetic: base positions are gated into the core (lanes whose coordinate the gate
+  // would have had to fold make the tile unclean, whatever this says)
+  const unsigned bw = (unsigned)b.mxx - (unsigned)b.mnx + ORDER, bh = (unsigned)b.mxy - (unsigned)b.mny + ORDER;
+  return bw <= 64u && bh <= (unsigned)EU5_TEXELS && bw * bh <= (unsigned)EU5_TEXELS;
+}
+
+// gate arithmetic without the per-lane range test (map.h:341-357, :423-440): a coordinate that needs
+// folding ends up outside the core, which eu5_tile reads off the tile's box with scalar compares
+__device__ __forceinline__ eu_f2 eu5_gate2(eu_f2 c, int kind, float lower, float upper)
+{
+  if (kind == 0) {            // clamp_gate, map.h:231-236
+    eu_f2 r = c;
+    r = eu_sel2(c < lower, (eu_f2){ lower, lower }, r);
+    r = eu_sel2(c > upper, (eu_f2){ upper, upper }, r);
+    return r;
+  }
+  eu_f2 cc = c - lower;
+  if (kind == 1) cc = eu_abs2(cc);
+  return cc + lower;
+}
+
+// -1 for a lane whose |a|, |b|, |c| are not all inside [2^-40, 2^40] (the range the FMA division
+// and square root sequences are used in; a NaN cannot occur: the stepper tables are finite)
+__device__ __forceinline__ int eu5_out_of_range3(float a, float b, float c)
+{
+  const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+  const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+  return (hi <= 0x1p40f && lo >= 0x1p-40f) ? 0 : -1;
 }
 
 // FAST: the job's uniform switches as compile-time constants - 'ray = B * c0 + A' without
@@ -598,6 +645,10 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
   constexpr int TEX = 4;
   constexpr int order = DEG + 1;
   const eu_src_dev &s = p.src;
+#ifdef EU5_STAMPS
+  unsigned long long st_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+  EU5_STAMP(0);
   const int pr = lane & 3, rw = (lane >> 2) & 7, hf = lane >> 5;
   const int y = p.row_begin + tile_y * EU4_TH + rw;
   const bool yin = y < p.row_end;
@@ -611,7 +662,59 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
   eu_i2 hit, ok = { -1, -1 };
   int ixa, ixb;
   eu_f2 wx[order], wy[order];
-  if constexpr (HOIST) {
+  constexpr bool LEAN = FAST && PRJ == EU_SPHERICAL;
+  if constexpr (LEAN) {
+    // the reference's operations in the reference's order (stepper.h ray, geometry.h:278-301,
+    // environment.h:988-1006, map.h gates) in their leanest instruction forms (eu_math2.h, round 3)
+    hit = (eu_i2){ -1, -1 };
+    eu_i2 big0 = { 0, 0 }, big1 = { 0, 0 };
+    eu_f2 lat;
+    if constexpr (HOIST) {
+      const float4 *ea = (const float4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
+      const float4 *eb = (const float4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
+      const float4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
+      const float A1 = rt[1], B1 = rt[4];
+      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      const eu_f2 ryy = B1 * c0 + A1;
+      ixa = __float_as_int(a0.x); ixb = __float_as_int(b0.x);
+      tx = (eu_f2){ a0.y, b0.y };
+      if constexpr (DEG >= 2) {
+        wx[0] = (eu_f2){ a0.z, b0.z }; wx[1] = (eu_f2){ a0.w, b0.w }; wx[2] = (eu_f2){ a1.x, b1.x };
+        if constexpr (DEG == 3) wx[3] = (eu_f2){ a1.y, b1.y };
+      }
+      const eu_f2 qs = { a1.z, b1.z };
+      ok = (eu_i2){ (ixa != INT_MIN ? -1 : 0) & ~eu5_out_of_range3(ryy.x, qs.x, qs.x),
+                    (ixb != INT_MIN ? -1 : 0) & ~eu5_out_of_range3(ryy.y, qs.y, qs.y) };
+      lat = eu_atan2f_2_lean(ryy, qs, atab, 1, big0);
+    } else {
+      const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
+      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      const eu_f2 rx = B0 * c0 + A0, ry = B1 * c0 + A1, rz = B2 * c0 + A2;
+      ok = (eu_i2){ ~eu5_out_of_range3(rx.x, ry.x, rz.x), ~eu5_out_of_range3(rx.y, ry.y, rz.y) };
+      const eu_f2 q2 = rx * rx + rz * rz;
+      const eu_f2 qs = eu_sqrt2_safe(q2);
+      lat = eu_atan2f_2_lean(ry, qs, atab, 1, big0);
+      const eu_f2 lon = eu_atan2f_2_lean(rx, rz, atab, 0, big1);
+      eu_f2 i0 = { (float)((double)lon.x - s.tex_x0), (float)((double)lon.y - s.tex_x0) };
+      if (s.cdiv_ok) i0 = eu_div2_const(i0, s.ext_w, s.rcp_ext_w);
+      else i0 = eu_div2_rr(i0, s.ext_w, eu_rcp_refined(s.ext_w));
+      i0 = i0 * s.total_w; i0 = i0 - .5f;
+      const eu_f2 sx = i0 - s.win_x_off;
+      const eu_f2 gx = eu5_gate2(sx, s.gate0, s.lower0, s.upper0);
+      eu_f2 fx;
+      if constexpr (DEG & 1) fx = (eu_f2){ floorf(gx.x), floorf(gx.y) };
+      else fx = (eu_f2){ roundf(gx.x), roundf(gx.y) };
+      tx = gx - fx;
+      ixa = (int)fx.x; ixb = (int)fx.y;
+    }
+    ok = ok & ~(big0 | big1);
+    eu_f2 i1 = { (float)((double)lat.x - s.tex_y0), (float)((double)lat.y - s.tex_y0) };
+    if (s.cdiv_ok) i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
+    else i1 = eu_div2_rr(i1, s.ext_h, eu_rcp_refined(s.ext_h));
+    i1 = i1 * s.total_h; i1 = i1 - .5f;
+    const eu_f2 sy = i1 - s.win_y_off;
+    gy = eu5_gate2(sy, s.gate1, s.lower1, s.upper1);
+  } else if constexpr (HOIST) {
     const float4 *ea = (const float4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
     const float4 *eb = (const float4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
     const float4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
@@ -677,6 +780,10 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
   else fy = (eu_f2){ roundf(gy.x), roundf(gy.y) };
   ty = gy - fy;
   const int iya = (int)fy.x, iyb = (int)fy.y;
+#ifdef EU5_STAMPS
+  asm volatile("" : : "v"(iya), "v"(iyb), "v"(ixa), "v"(ixb));
+#endif
+  EU5_STAMP(2);
 
   // boxes of the base positions of the hitting pixels: quarters (q*, lane 15 of every row of 16
   // lanes), halves (h*, lanes 31 and 63), tile
@@ -685,7 +792,19 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
   if (hit.y) { q0 = min(q0, ixb); q2 = max(q2, ixb); q1 = min(q1, iyb); q3 = max(q3, iyb); }
   eu5_box_reduce(q0, q1, q2, q3, h0, h1, h2, h3);
   const eu5_box full = eu5_box_join(eu5_box_at(h0, h1, h2, h3, 31), eu5_box_at(h0, h1, h2, h3, 63));
-  const bool clean = __ballot((hit.x && !ok.x) || (hit.y && !ok.y)) == 0ull;
+  bool clean = __ballot((hit.x && !ok.x) || (hit.y && !ok.y)) == 0ull;
+  if constexpr (LEAN) {
+    // the gates' range tests, on the box: a coordinate the periodic gate folds (c < lower or
+    // c - lower >= width) leaves ix <= -1 or ix >= width - 1, one the mirror gate folds from
+    // above ix >= width - 1 (a superset: the tiles on the seam, which do not fit anyway)
+    const int cw = (int)(s.upper0 + 0.5f), ch = (int)(s.upper1 + 0.5f);
+    if (full.mnx != INT_MAX) {
+      if (s.gate0 == 2 && full.mnx < 0) clean = false;
+      if (s.gate0 != 0 && full.mxx >= cw - 1) clean = false;
+      if (s.gate1 == 2 && full.mny < 0) clean = false;
+      if (s.gate1 != 0 && full.mxy >= ch - 1) clean = false;
+    }
+  }
   // passes: the tile at once, its halves or its quarters, whichever fits the slice first
   int npass = 1;
   const int f = eu5_box_fits<order>(full);
@@ -699,6 +818,7 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
         npass = -1;
     }
   }
+  EU5_STAMP(3);
   float *const orow = p.out + (long long)(yc - p.row_begin) * p.out_stride;
   if (npass < 0 || (npass > 0 && !clean)) {
     // not even the quarters fit (the pole of a lat/lon source, the +-180 degree seam, strong
@@ -714,10 +834,6 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
   }
   eu_f2 rga = { 0.0f, 0.0f }, bxa = { 0.0f, 0.0f }, rgb = { 0.0f, 0.0f }, bxb = { 0.0f, 0.0f };
   if (npass > 0) {
-    if constexpr (DEG >= 2) {
-      eu_weights2<DEG>(s.wm, ty, wy);
-      if constexpr (!HOIST) eu_weights2<DEG>(s.wm, tx, wx);
-    }
     const unsigned lds_tile = (unsigned)(unsigned long long)(eu4_lds_void)wtile;
     const int grp = npass == 1 ? 0 : npass == 2 ? hf : (lane >> 4);
 #pragma unroll 1
@@ -731,24 +847,53 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
       }
       if (bx.mnx == INT_MAX) continue;               // a half / quarter without a hitting pixel
       const int ibw = bx.mxx - bx.mnx + order, ibh = bx.mxy - bx.mny + order;
-      if (lane < ibw) {
+      {
+        // stage the box: lane L fetches the texel of box column L % ibw in row L / ibw of the k = 64 / ibw
+        // rows ONE LDS-DMA instruction covers (an LDS-DMA instruction costs its wave 60-180 cycles of issue
+        // whatever it moves: one per box row was 14-25 per tile); the LDS image is the box, rows back to back
+        const unsigned tv = eu5_divtab.v[ibw];
+        const int k = (int)(tv >> 24);
+        const unsigned r = ((unsigned)lane * (tv & 0x1ffffu)) >> 16, c = (unsigned)lane - r * (unsigned)ibw;
         const int bx0 = bx.mnx - DEG / 2, by0 = bx.mny - DEG / 2;
-        const unsigned voff = (unsigned)(lane * NCH) * 4u;
+        const unsigned pitchb = (unsigned)(s.es1 * 4);
+        const unsigned voff = r * pitchb + c * (NCH * 4u);
         const char *sb = (const char *)(s.base + ((long long)by0 * s.es1 + (long long)bx0 * NCH));
-        const long long step = s.es1 * 4;
+        const unsigned long long step = (unsigned long long)k * pitchb;
         unsigned dst = lds_tile;
-        const unsigned dstep = (unsigned)ibw * (TEX * 4u);
+        const unsigned dstep = (unsigned)(k * ibw) * (TEX * 4u);
+        int left = ibh;
+        if ((int)r < k) {
 #pragma unroll 1
-        for (int it = 0; it < ibh; it++) { eu4_dma_row(dst, voff, sb); sb += step; dst += dstep; }
+          for (; left >= k; left -= k) { eu4_dma_row(dst, voff, sb); sb += step; dst += dstep; }
+        }
+        left = ibh % k;
+        if ((int)r < left) {
+          const int full = ibh / k;     // the loop above ran on other lanes only: recompute its end
+          eu4_dma_row(lds_tile + (unsigned)full * dstep, voff,
+                      (const char *)(s.base + ((long long)by0 * s.es1 + (long long)bx0 * NCH)) + (unsigned long long)full * step);
+        }
+      }
+      if (pi == 0) {
+        // the weights, behind the DMA issue
+        if constexpr (DEG >= 2) {
+          eu_weights2<DEG>(s.wm, ty, wy);
+          if constexpr (!HOIST) eu_weights2<DEG>(s.wm, tx, wx);
+        }
       }
       // lanes of other groups and lanes without a hit read the box origin
       const bool mine = grp == pi;
       const int oa = (mine && hit.x) ? ((iya - bx.mny) * ibw + (ixa - bx.mnx)) * TEX : 0;
       const int ob = (mine && hit.y) ? ((iyb - bx.mny) * ibw + (ixb - bx.mnx)) * TEX : 0;
+      if (pi == 0) EU5_STAMP(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (pi == 0) EU5_STAMP(5);
       if (mine) eu5_taps<NCH, DEG>((eu_lptr)wtile, oa, ob, ibw * TEX, wx, wy, tx, ty, rga, bxa, rgb, bxb);
     }
   }
+#ifdef EU5_STAMPS
+  asm volatile("" : : "v"(rga), "v"(bxa), "v"(rgb), "v"(bxb));
+#endif
+  EU5_STAMP(6);
   // environment::eval brighten (environment.h:1821-1842), zero on a miss; storer
   float qa[4] = { rga.x, rga.y, bxa.x, bxa.y }, qb[4] = { rgb.x, rgb.y, bxb.x, bxb.y };
   constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
@@ -762,6 +907,15 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
   }
   if (va) eu_put<NCH>(orow, xa, qa);
   if (vb) eu_put<NCH>(orow, xb, qb);
+  EU5_STAMP(7);
+#ifdef EU5_STAMPS
+  if (lane == 0 && w.stamps) {
+    unsigned long long *o = w.stamps + ((size_t)tile_y * w.tiles16 + x0 / EU4_TW) * 8;
+    st_[1] = (unsigned long long)(npass + 1) | (HOIST ? 16ull : 0ull);
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = st_[k];
+  }
+#endif
 }
 
 // grid: 8 * (workgroups per XCD); the launcher sizes it to what is resident at once
@@ -770,13 +924,13 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
 {
   __shared__ __attribute__((aligned(16))) float tile_all[EU5_WAVES * EU5_TEXELS * 4];
   __shared__ __attribute__((aligned(16))) float atab[768];
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *const tile = tile_all + wave * (EU5_TEXELS * 4);
   if (PRJ != EU_CUBEMAP && wave == 0) {
 #pragma unroll
     for (int i = 0; i < 3; i++)
-      __builtin_amdgcn_global_load_lds((eu4_gbl_void)(w.atab_g + i * 256 + lane * 4),
+      __builtin_amdgcn_global_load_lds((eu4_gbl_void)(w.atab_g + i * 256 + lane0 * 4),
                                        (eu4_lds_void)(atab + i * 256), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -799,6 +953,10 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
     if (unit >= units) break;
     const int tile_y = unit * EU5_UNIT_ROWS + ry;
     if (tile_y < p.tiles_y) {
+      // everything a tile derives from the lane index is recomputed per tile (kept live across the
+      // loop it costs registers the tile code needs)
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
       const int plan = PRJ == EU_SPHERICAL ? w.tileplan[tile_y] : -1;
       if (plan >= 0)
         eu5_tile<NCH, DEG, PRJ, PRJ == EU_SPHERICAL, FAST>(p, w, atab, tile, w.coltab + (size_t)plan * p.width * EU4_COL_FLOATS,
@@ -957,8 +1115,13 @@ static int launch4_ndp(const eu_render_params &p, const eu4_plan &w, hipStream_t
       if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
       return n;
     }();
+    // eu_div2_rr's range: the divisor in [2^-20, 2^20], the extent's origin 0 or in that range (so that a
+    // non-zero difference 'angle - origin' is at least 2^-73)
+    auto mag_ok = [](double v) { const double a = v < 0 ? -v : v; return a == 0.0 || (a >= 0x1p-20 && a <= 0x1p20); };
     const bool fast = p.form == EU_FORM_BA && p.norm_mode == EU_NORM_NONE && p.band_count <= 1 && p.src.brighten == 1.0f &&
-                      (p.src.prj != EU_SPHERICAL || (p.src.always_hit && p.src.cdiv_ok));
+                      (p.src.prj != EU_SPHERICAL ||
+                       (p.src.always_hit && mag_ok(p.src.tex_x0) && mag_ok(p.src.tex_y0) && p.src.ext_w >= 0x1p-20f &&
+                        p.src.ext_w <= 0x1p20f && p.src.ext_h >= 0x1p-20f && p.src.ext_h <= 0x1p20f && p.tab_finite));
     static const bool dbg = getenv("EU_HIP_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "eu_render5: fast %d (form %d norm %d bands %d brighten %g always_hit %d cdiv_ok %d)\n", (int)fast, p.form,
                      p.norm_mode, p.band_count, (double)p.src.brighten, p.src.always_hit, p.src.cdiv_ok);
@@ -1137,9 +1300,39 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
   }
   w.tileplan = g4.tileplan;
   w.coltab = g4.coltab;
+#ifdef EU5_STAMPS
+  // diagnostic build: stamps of every tile, averaged per pass count / plan kind after the launch
+  static unsigned long long *d_st = nullptr; static size_t st_cap = 0; static int dumps = 0;
+  const size_t nst = (size_t)w.tiles16 * p.tiles_y * 8;
+  if (st_cap < nst) { if (d_st) (void)hipFree(d_st); if (hipMalloc((void **)&d_st, nst * 8) != hipSuccess) return -1; st_cap = nst; }
+  (void)hipMemsetAsync(d_st, 0, nst * 8, st);
+  w.stamps = d_st;
+  int rc_ = p.nch == 3 ? launch4_n<3>(p, w, st) : p.nch == 4 ? launch4_n<4>(p, w, st) : 1;
+  if (rc_ == 0 && dumps < 2 && nst >= 8 * 4096) {
+    dumps++;
+    std::vector<unsigned long long> h(nst);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), d_st, nst * 8, hipMemcpyDeviceToHost);
+    double acc[32][8] = {}; size_t cnt[32] = {};
+    for (size_t t = 0; t < nst / 8; t++) {
+      const unsigned long long *q = &h[t * 8];
+      if (!q[0] || !q[7]) continue;
+      const int cls = (int)(q[1] & 31);
+      cnt[cls]++;
+      acc[cls][0] += (double)(q[2] - q[0]); acc[cls][1] += (double)(q[3] - q[2]);
+      if (q[4]) { acc[cls][2] += (double)(q[4] - q[3]); acc[cls][3] += (double)(q[5] - q[4]); acc[cls][4] += (double)(q[6] - q[5]); }
+      acc[cls][5] += (double)(q[7] - q[6]); acc[cls][6] += (double)(q[7] - q[0]);
+    }
+    for (int c = 0; c < 32; c++) if (cnt[c])
+      fprintf(stderr, "eu5 stamps: hoist %d npass %2d tiles %8zu | coords %7.0f box %6.0f dma-issue+weights %6.0f dma-wait %6.0f taps(all passes) %6.0f store %5.0f | tile %7.0f (100 MHz ticks? s_memtime)\n",
+              c >> 4, (c & 15) - 1, cnt[c], acc[c][0] / cnt[c], acc[c][1] / cnt[c], acc[c][2] / cnt[c], acc[c][3] / cnt[c], acc[c][4] / cnt[c], acc[c][5] / cnt[c], acc[c][6] / cnt[c]);
+  }
+  return rc_;
+#else
   switch (p.nch) {
     case 3: return launch4_n<3>(p, w, st);
     case 4: return launch4_n<4>(p, w, st);
   }
   return 1;
+#endif
 }
