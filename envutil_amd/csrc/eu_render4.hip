@@ -205,7 +205,16 @@ struct eu4_plan {
   const int *tileplan;    // per tile row of the launch: column table to use, -1: none
   const float *coltab;    // [plan][width][EU4_COL_FLOATS]
   int tiles16;            // wave tiles per tile row
+#ifdef EU5_STAMPS
+  unsigned long long *stamps;   // diagnostic build: 8 s_memtime stamps per tile of eu_render5_kernel
+#endif
 };
+
+#ifdef EU5_STAMPS
+#define EU5_STAMP(k) do { asm volatile("" ::: "memory"); st_[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define EU5_STAMP(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // one tile of the staged kernel. HOIST: the x half of the coordinate chain comes from the
@@ -772,9 +781,39 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
   }
   w.tileplan = g4.tileplan;
   w.coltab = g4.coltab;
+#ifdef EU5_STAMPS
+  // diagnostic build: stamps of every tile, averaged per pass count / plan kind after the launch
+  static unsigned long long *d_st = nullptr; static size_t st_cap = 0; static int dumps = 0;
+  const size_t nst = (size_t)w.tiles16 * p.tiles_y * 8;
+  if (st_cap < nst) { if (d_st) (void)hipFree(d_st); if (hipMalloc((void **)&d_st, nst * 8) != hipSuccess) return -1; st_cap = nst; }
+  (void)hipMemsetAsync(d_st, 0, nst * 8, st);
+  w.stamps = d_st;
+  int rc_ = p.nch == 3 ? launch4_n<3>(p, w, st) : p.nch == 4 ? launch4_n<4>(p, w, st) : 1;
+  if (rc_ == 0 && dumps < 2 && nst >= 8 * 4096) {
+    dumps++;
+    std::vector<unsigned long long> h(nst);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), d_st, nst * 8, hipMemcpyDeviceToHost);
+    double acc[32][8] = {}; size_t cnt[32] = {};
+    for (size_t t = 0; t < nst / 8; t++) {
+      const unsigned long long *q = &h[t * 8];
+      if (!q[0] || !q[7]) continue;
+      const int cls = (int)(q[1] & 31);
+      cnt[cls]++;
+      acc[cls][0] += (double)(q[2] - q[0]); acc[cls][1] += (double)(q[3] - q[2]);
+      if (q[4]) { acc[cls][2] += (double)(q[4] - q[3]); acc[cls][3] += (double)(q[5] - q[4]); acc[cls][4] += (double)(q[6] - q[5]); }
+      acc[cls][5] += (double)(q[7] - q[6]); acc[cls][6] += (double)(q[7] - q[0]);
+    }
+    for (int c = 0; c < 32; c++) if (cnt[c])
+      fprintf(stderr, "eu5 stamps: hoist %d npass %2d tiles %8zu | coords %7.0f box %6.0f dma-issue+weights %6.0f dma-wait %6.0f taps(all passes) %6.0f store %5.0f | tile %7.0f (100 MHz ticks? s_memtime)\n",
+              c >> 4, (c & 15) - 1, cnt[c], acc[c][0] / cnt[c], acc[c][1] / cnt[c], acc[c][2] / cnt[c], acc[c][3] / cnt[c], acc[c][4] / cnt[c], acc[c][5] / cnt[c], acc[c][6] / cnt[c]);
+  }
+  return rc_;
+#else
   switch (p.nch) {
     case 3: return launch4_n<3>(p, w, st);
     case 4: return launch4_n<4>(p, w, st);
   }
   return 1;
+#endif
 }

@@ -27,7 +27,8 @@
 #define EU5_TEXELS 576      // LDS texels (16 bytes) per wave: 4 x 9 KB + 3 KB table = 39 KB per workgroup, 4 per CU
 #endif
 #ifndef EU5_OCC
-#define EU5_OCC 4           // waves per SIMD the registers are capped for (128: at 96 the tile code spills, and every scratch access costs more than the fifth wave gives)
+#define EU5_OCC 4           // waves per SIMD the registers are capped for (128: at 96 the tile code spills, and every
+                            // scratch access costs more than the fifth wave gives: 2.06 ms with 42 of them per tile)
 #endif
 #ifndef EU5_UNIT_ROWS
 #define EU5_UNIT_ROWS 4     // tile rows per XCD unit
@@ -185,114 +186,65 @@ __device__ __forceinline__ int eu5_out_of_range3(float a, float b, float c)
 }
 
 // FAST: the job's uniform switches as compile-time constants - 'ray = B * c0 + A' without
-// normalisation, no bands, every ray hits, brighten 1 (what a cubemap / rectilinear target of a
-// full-sphere or cubemap source is). The persistent loop keeps every scalar it uses live: fewer of
-// them means fewer SGPR spills in the tile code.
-//
-// The tile code is cut into stages so that the loop can run them SKEWED (software pipelining over
-// the tiles of a wave):   load(t+1) | box(t) | DMA issue(t) | coordinates(t+1) | taps(t), store(t)
-// The LDS-DMA of tile t is in flight under the coordinate chain of tile t+1 (~2-7k cycles of vector
-// work: the round trip to HBM hides completely), the table loads of tile t+1 under the box
-// reduction of tile t. vmcnt counts in issue order, so nothing that tile t+1's chain waits for may be
-// younger than tile t's DMA: its loads are issued before it and consumed (eu5_settle) before it.
-
-struct eu5_loaded {           // what the table loads of a tile return (20 registers, two readings)
-  eu4_f4 a0, a1, b0, b1;      // HOIST: the column entries of the lane's two pixels
-                              // otherwise: a0 = (A0, A2, B0, B2), a1 = (C0, C1, C2, -), b0.xy = c1
-  eu_f2 c0;                   // column table of the stepper
-  float A1, B1;               // row constants of the lane's row
-  int valid;                  // bit 3 / 4: pixel a / b lies inside the frame
-};
-
-template <int DEG, bool HOIST>
-struct eu5_coord {            // what the coordinate stage hands to the evaluation stage
-  int ixa, ixb, iya, iyb;     // base positions (split: basis.h:102-146)
-  eu_f2 ty;                   // fractional part
-  eu_f2 wx[(HOIST && DEG >= 2) ? DEG + 1 : 1];   // HOIST, degree >= 2: the x weights (pixel a, pixel b) of the column
-                              // table; otherwise wx[0] = tx (the weights are formed by the evaluation stage)
-  int flags;                  // bit 0 / 1: pixel a / b hits, bit 2: a hitting pixel left the fast path,
-                              // bit 3 / 4: pixel a / b lies inside the frame
-};
-
-// the consumer the compiler has to see before the DMA is issued
-__device__ __forceinline__ void eu5_settle(eu5_loaded &L)
+// normalisation, no bands, every ray hits, the verified constant division, brighten 1 (what a
+// cubemap / rectilinear target of a full-sphere or cubemap source is). The persistent loop keeps
+// every scalar it uses live: fewer of them means no SGPR spills in the tile code.
+template <int NCH, int DEG, int PRJ, bool HOIST, bool FAST>
+__device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_plan &w, const float *atab,
+                                         float *wtile, const float *ct, int tile_y, int x0, int lane)
 {
-  asm volatile("" : "+v"(L.a0), "+v"(L.a1), "+v"(L.b0), "+v"(L.b1), "+v"(L.c0), "+v"(L.A1), "+v"(L.B1));
-}
-
-// lane -> pixels of the tile: [half | row | pair]
-struct eu5_where { int xa, xb, xac, xbc, yc; bool va, vb; };
-__device__ __forceinline__ eu5_where eu5_locate(const eu_render_params &p, int tile_y, int x0, int lane)
-{
-  eu5_where q;
+  constexpr int TEX = 4;
+  constexpr int order = DEG + 1;
+  const eu_src_dev &s = p.src;
+#ifdef EU5_STAMPS
+  unsigned long long st_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+  EU5_STAMP(0);
   const int pr = lane & 3, rw = (lane >> 2) & 7, hf = lane >> 5;
   const int y = p.row_begin + tile_y * EU4_TH + rw;
   const bool yin = y < p.row_end;
-  q.yc = yin ? y : p.row_end - 1;
-  q.xa = x0 + 8 * hf + 2 * pr; q.xb = q.xa + 1;
-  q.va = yin && q.xa < p.width; q.vb = yin && q.xb < p.width;
-  q.xac = q.xa < p.width ? q.xa : p.width - 1; q.xbc = q.xb < p.width ? q.xb : p.width - 1;
-  return q;
-}
+  const int yc = yin ? y : p.row_end - 1;
+  const float *rt = p.row + (long long)(FAST ? yc : eu_frame_row(yc, p.band_shift, p.band_count, p.band_index)) * EU_ROW_FLOATS;
+  const int xa = x0 + 8 * hf + 2 * pr, xb = xa + 1;
+  const bool va = yin && xa < p.width, vb = yin && xb < p.width;
+  const int xac = xa < p.width ? xa : p.width - 1, xbc = xb < p.width ? xb : p.width - 1;
 
-template <bool HOIST, bool FAST>
-__device__ __forceinline__ void eu5_load(const eu_render_params &p, const float *ct, int tile_y, int x0, int lane, eu5_loaded &L)
-{
-  const eu5_where q = eu5_locate(p, tile_y, x0, lane);
-  const float *rt = p.row + (long long)(FAST ? q.yc : eu_frame_row(q.yc, p.band_shift, p.band_count, p.band_index)) * EU_ROW_FLOATS;
-  L.c0 = (eu_f2){ p.col[q.xac], p.col[q.xbc] };
-  L.A1 = rt[1]; L.B1 = rt[4];
-  L.valid = (q.va ? 8 : 0) | (q.vb ? 16 : 0);
-  if constexpr (HOIST) {
-    const eu4_f4 *ea = (const eu4_f4 *)(ct + (size_t)q.xac * EU4_COL_FLOATS);
-    const eu4_f4 *eb = (const eu4_f4 *)(ct + (size_t)q.xbc * EU4_COL_FLOATS);
-    L.a0 = ea[0]; L.a1 = ea[1]; L.b0 = eb[0]; L.b1 = eb[1];
-  } else {
-    L.a0 = (eu4_f4){ rt[0], rt[2], rt[3], rt[5] };
-    if (!FAST && p.form == EU_FORM_BCA) {
-      L.a1 = (eu4_f4){ rt[6], rt[7], rt[8], 0.0f };
-      const float *colB = p.col + p.width;
-      L.b0.x = colB[q.xac]; L.b0.y = colB[q.xbc];
-    }
-  }
-}
-
-template <int NCH, int DEG, int PRJ, bool HOIST, bool FAST>
-__device__ __forceinline__ void eu5_coords(const eu_render_params &p, const float *atab, const eu5_loaded &L,
-                                           int tile_y, int x0, int lane, eu5_coord<DEG, HOIST> &C)
-{
-  const eu_src_dev &s = p.src;
-  eu_f2 gy, tx;
-  eu_i2 hit = { -1, -1 }, ok = { -1, -1 };
+  eu_f2 tx, ty, gy;
+  eu_i2 hit, ok = { -1, -1 };
+  int ixa, ixb;
+  eu_f2 wx[order], wy[order];
   constexpr bool LEAN = FAST && PRJ == EU_SPHERICAL;
-  if constexpr (HOIST) {
-    C.ixa = __float_as_int(L.a0.x); C.ixb = __float_as_int(L.b0.x);
-    tx = (eu_f2){ L.a0.y, L.b0.y };
-    if constexpr (DEG >= 2) {
-      C.wx[0] = (eu_f2){ L.a0.z, L.b0.z }; C.wx[1] = (eu_f2){ L.a0.w, L.b0.w }; C.wx[2] = (eu_f2){ L.a1.x, L.b1.x };
-      if constexpr (DEG == 3) C.wx[3] = (eu_f2){ L.a1.y, L.b1.y };
-    }
-  }
   if constexpr (LEAN) {
     // the reference's operations in the reference's order (stepper.h ray, geometry.h:278-301,
     // environment.h:988-1006, map.h gates) in their leanest instruction forms (eu_math2.h, round 3)
+    hit = (eu_i2){ -1, -1 };
     eu_i2 big0 = { 0, 0 }, big1 = { 0, 0 };
     eu_f2 lat;
     if constexpr (HOIST) {
-      const eu_f2 ryy = L.B1 * L.c0 + L.A1;
-      const eu_f2 qs = { L.a1.z, L.b1.z };
-      ok = (eu_i2){ (C.ixa != INT_MIN ? -1 : 0) & ~eu5_out_of_range3(ryy.x, qs.x, qs.x),
-                    (C.ixb != INT_MIN ? -1 : 0) & ~eu5_out_of_range3(ryy.y, qs.y, qs.y) };
+      const float4 *ea = (const float4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
+      const float4 *eb = (const float4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
+      const float4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
+      const float A1 = rt[1], B1 = rt[4];
+      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      const eu_f2 ryy = B1 * c0 + A1;
+      ixa = __float_as_int(a0.x); ixb = __float_as_int(b0.x);
+      tx = (eu_f2){ a0.y, b0.y };
+      if constexpr (DEG >= 2) {
+        wx[0] = (eu_f2){ a0.z, b0.z }; wx[1] = (eu_f2){ a0.w, b0.w }; wx[2] = (eu_f2){ a1.x, b1.x };
+        if constexpr (DEG == 3) wx[3] = (eu_f2){ a1.y, b1.y };
+      }
+      const eu_f2 qs = { a1.z, b1.z };
+      ok = (eu_i2){ (ixa != INT_MIN ? -1 : 0) & ~eu5_out_of_range3(ryy.x, qs.x, qs.x),
+                    (ixb != INT_MIN ? -1 : 0) & ~eu5_out_of_range3(ryy.y, qs.y, qs.y) };
       lat = eu_atan2f_2_lean(ryy, qs, atab, 1, big0);
     } else {
-      const float A0 = L.a0.x, A2 = L.a0.y, B0 = L.a0.z, B2 = L.a0.w;
-      const eu_f2 rx = B0 * L.c0 + A0, ry = L.B1 * L.c0 + L.A1, rz = B2 * L.c0 + A2;
+      const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
+      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      const eu_f2 rx = B0 * c0 + A0, ry = B1 * c0 + A1, rz = B2 * c0 + A2;
       ok = (eu_i2){ ~eu5_out_of_range3(rx.x, ry.x, rz.x), ~eu5_out_of_range3(rx.y, ry.y, rz.y) };
       const eu_f2 q2 = rx * rx + rz * rz;
       const eu_f2 qs = eu_sqrt2_safe(q2);
       lat = eu_atan2f_2_lean(ry, qs, atab, 1, big0);
-      // one chain after the other: interleaved they need more registers than the loop has to spare
-      __builtin_amdgcn_sched_barrier(0);
       const eu_f2 lon = eu_atan2f_2_lean(rx, rz, atab, 0, big1);
       eu_f2 i0 = { (float)((double)lon.x - s.tex_x0), (float)((double)lon.y - s.tex_x0) };
       if (s.cdiv_ok) i0 = eu_div2_const(i0, s.ext_w, s.rcp_ext_w);
@@ -304,7 +256,7 @@ __device__ __forceinline__ void eu5_coords(const eu_render_params &p, const floa
       if constexpr (DEG & 1) fx = (eu_f2){ floorf(gx.x), floorf(gx.y) };
       else fx = (eu_f2){ roundf(gx.x), roundf(gx.y) };
       tx = gx - fx;
-      C.ixa = (int)fx.x; C.ixb = (int)fx.y;
+      ixa = (int)fx.x; ixb = (int)fx.y;
     }
     ok = ok & ~(big0 | big1);
     eu_f2 i1 = { (float)((double)lat.x - s.tex_y0), (float)((double)lat.y - s.tex_y0) };
@@ -314,38 +266,54 @@ __device__ __forceinline__ void eu5_coords(const eu_render_params &p, const floa
     const eu_f2 sy = i1 - s.win_y_off;
     gy = eu5_gate2(sy, s.gate1, s.lower1, s.upper1);
   } else if constexpr (HOIST) {
-    const eu_f2 ryy = L.B1 * L.c0 + L.A1;
-    ok = ok & (eu_i2){ C.ixa != INT_MIN ? -1 : 0, C.ixb != INT_MIN ? -1 : 0 };
-    const eu_f2 qs = { L.a1.z, L.b1.z };
+    const float4 *ea = (const float4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
+    const float4 *eb = (const float4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
+    const float4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
+    const float A1 = rt[1], B1 = rt[4];
+    const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+    const eu_f2 ryy = B1 * c0 + A1;
+    ixa = __float_as_int(a0.x); ixb = __float_as_int(b0.x);
+    ok = ok & (eu_i2){ ixa != INT_MIN ? -1 : 0, ixb != INT_MIN ? -1 : 0 };
+    tx = (eu_f2){ a0.y, b0.y };
+    if constexpr (DEG >= 2) {
+      wx[0] = (eu_f2){ a0.z, b0.z }; wx[1] = (eu_f2){ a0.w, b0.w }; wx[2] = (eu_f2){ a1.x, b1.x };
+      if constexpr (DEG == 3) wx[3] = (eu_f2){ a1.y, b1.y };
+    }
+    const eu_f2 qs = { a1.z, b1.z };
     const eu_f2 lat = eu_atan2f_2_tab_ok(ryy, qs, atab, 1, ok);
+    hit = (eu_i2){ -1, -1 };
     if (!FAST && !s.always_hit) {
-      const eu_f2 lon = { L.a1.w, L.b1.w };
+      const eu_f2 lon = { a1.w, b1.w };
       hit = (lon >= s.wex0) & (lon <= s.wex1) & (lat >= s.wex2) & (lat <= s.wex3);
     }
     eu_f2 i1 = { (float)((double)lat.x - s.tex_y0), (float)((double)lat.y - s.tex_y0) };
-    if (s.cdiv_ok) i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
+    if (FAST || s.cdiv_ok) i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
     else i1 = i1 / s.ext_h;
     i1 = i1 * s.total_h; i1 = i1 - .5f;
     const eu_f2 sy = i1 - s.win_y_off;
     gy = eu_gate2_ok(sy, s.gate1, s.lower1, s.upper1, ok);
   } else {
     eu_ray2 r;
-    const float A0 = L.a0.x, A2 = L.a0.y, B0 = L.a0.z, B2 = L.a0.w;
-    if (!FAST && p.form == EU_FORM_BCA) {
-      const float C0 = L.a1.x, C1 = L.a1.y, C2 = L.a1.z;
-      const eu_f2 c1 = { L.b0.x, L.b0.y };
-      r.x = B0 * L.c0 + C0 * c1 + A0;
-      r.y = L.B1 * L.c0 + C1 * c1 + L.A1;
-      r.z = B2 * L.c0 + C2 * c1 + A2;
-    } else {
-      r.x = B0 * L.c0 + A0;
-      r.y = L.B1 * L.c0 + L.A1;
-      r.z = B2 * L.c0 + A2;
-    }
-    if (!FAST && p.norm_mode == EU_NORM_DIV) {
-      eu_f2 sqn = r.x * r.x; sqn = sqn + r.y * r.y; sqn = sqn + r.z * r.z;
-      const eu_f2 n = { sqrtf(sqn.x), sqrtf(sqn.y) };
-      r.x = r.x / n; r.y = r.y / n; r.z = r.z / n;
+    {
+      const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
+      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      if (!FAST && p.form == EU_FORM_BCA) {
+        const float C0 = rt[6], C1 = rt[7], C2 = rt[8];
+        const float *colB = p.col + p.width;
+        const eu_f2 c1 = { colB[xac], colB[xbc] };
+        r.x = B0 * c0 + C0 * c1 + A0;
+        r.y = B1 * c0 + C1 * c1 + A1;
+        r.z = B2 * c0 + C2 * c1 + A2;
+      } else {
+        r.x = B0 * c0 + A0;
+        r.y = B1 * c0 + A1;
+        r.z = B2 * c0 + A2;
+      }
+      if (!FAST && p.norm_mode == EU_NORM_DIV) {
+        eu_f2 sqn = r.x * r.x; sqn = sqn + r.y * r.y; sqn = sqn + r.z * r.z;
+        const eu_f2 n = { sqrtf(sqn.x), sqrtf(sqn.y) };
+        r.x = r.x / n; r.y = r.y / n; r.z = r.z / n;
+      }
     }
     eu_f2 sx, sy;
     hit = eu_coord2_ok<PRJ, FAST>(s, r, sx, sy, atab, ok);
@@ -355,57 +323,27 @@ __device__ __forceinline__ void eu5_coords(const eu_render_params &p, const floa
     if constexpr (DEG & 1) fx = (eu_f2){ floorf(gx.x), floorf(gx.y) };
     else fx = (eu_f2){ roundf(gx.x), roundf(gx.y) };
     tx = gx - fx;
-    C.ixa = (int)fx.x; C.ixb = (int)fx.y;
+    ixa = (int)fx.x; ixb = (int)fx.y;
   }
-  if constexpr (!HOIST || DEG < 2) C.wx[0] = tx;
-  hit = hit & (eu_i2){ (L.valid & 8) ? -1 : 0, (L.valid & 16) ? -1 : 0 };
+  hit = hit & (eu_i2){ va ? -1 : 0, vb ? -1 : 0 };
   eu_f2 fy;
   if constexpr (DEG & 1) fy = (eu_f2){ floorf(gy.x), floorf(gy.y) };
   else fy = (eu_f2){ roundf(gy.x), roundf(gy.y) };
-  C.ty = gy - fy;
-  C.iya = (int)fy.x; C.iyb = (int)fy.y;
-  C.flags = (hit.x ? 1 : 0) | (hit.y ? 2 : 0) | (((hit.x && !ok.x) || (hit.y && !ok.y)) ? 4 : 0) | L.valid;
-}
+  ty = gy - fy;
+  const int iya = (int)fy.x, iyb = (int)fy.y;
+#ifdef EU5_STAMPS
+  asm volatile("" : : "v"(iya), "v"(iyb), "v"(ixa), "v"(ixb));
+#endif
+  EU5_STAMP(2);
 
-// the boxes of a tile and what follows from them (scalars)
-struct eu5_plan1 {
-  eu5_box box0;                         // the box of pass 0
-  int npass;                            // 0: nothing hits, 1 / 2 / 4: passes, -1: left to the work list
-};
-
-// per-lane reduction registers: quarters (q*, lane 15 of every row of 16 lanes), halves (h*, lanes 31, 63)
-struct eu5_red { int q0, q1, q2, q3, h0, h1, h2, h3; };
-
-template <int DEG, bool HOIST>
-__device__ __forceinline__ void eu5_reduce(const eu5_coord<DEG, HOIST> &C, eu5_red &R)
-{
-  int q0 = INT_MAX, q1 = INT_MAX, q2 = INT_MIN, q3 = INT_MIN;
-  if (C.flags & 1) { q0 = C.ixa; q2 = C.ixa; q1 = C.iya; q3 = C.iya; }
-  if (C.flags & 2) { q0 = min(q0, C.ixb); q2 = max(q2, C.ixb); q1 = min(q1, C.iyb); q3 = max(q3, C.iyb); }
-  eu5_box_reduce(q0, q1, q2, q3, R.h0, R.h1, R.h2, R.h3);
-  R.q0 = q0; R.q1 = q1; R.q2 = q2; R.q3 = q3;
-}
-
-__device__ __forceinline__ eu5_box eu5_uniform(eu5_box b)
-{
-  // wave-uniform by construction; said explicitly, so that what derives from it (LDS-DMA bases, the
-  // division table's index) stays scalar
-  b.mnx = __builtin_amdgcn_readfirstlane(b.mnx); b.mny = __builtin_amdgcn_readfirstlane(b.mny);
-  b.mxx = __builtin_amdgcn_readfirstlane(b.mxx); b.mxy = __builtin_amdgcn_readfirstlane(b.mxy);
-  return b;
-}
-
-template <int DEG, bool HOIST, bool LEAN>
-__device__ __forceinline__ void eu5_boxes(const eu_render_params &p, const eu4_plan &w, const eu5_coord<DEG, HOIST> &C,
-                                          int tile_y, int x0, int lane, eu5_plan1 &B)
-{
-  constexpr int order = DEG + 1;
-  const eu_src_dev &s = p.src;
-  eu5_red R;
-  eu5_reduce<DEG, HOIST>(C, R);
-  const eu5_box half0 = eu5_box_at(R.h0, R.h1, R.h2, R.h3, 31), half1 = eu5_box_at(R.h0, R.h1, R.h2, R.h3, 63);
-  const eu5_box full = eu5_box_join(half0, half1);
-  bool clean = __ballot((C.flags & 4) != 0) == 0ull;
+  // boxes of the base positions of the hitting pixels: quarters (q*, lane 15 of every row of 16
+  // lanes), halves (h*, lanes 31 and 63), tile
+  int q0 = INT_MAX, q1 = INT_MAX, q2 = INT_MIN, q3 = INT_MIN, h0, h1, h2, h3;
+  if (hit.x) { q0 = ixa; q2 = ixa; q1 = iya; q3 = iya; }
+  if (hit.y) { q0 = min(q0, ixb); q2 = max(q2, ixb); q1 = min(q1, iyb); q3 = max(q3, iyb); }
+  eu5_box_reduce(q0, q1, q2, q3, h0, h1, h2, h3);
+  const eu5_box full = eu5_box_join(eu5_box_at(h0, h1, h2, h3, 31), eu5_box_at(h0, h1, h2, h3, 63));
+  bool clean = __ballot((hit.x && !ok.x) || (hit.y && !ok.y)) == 0ull;
   if constexpr (LEAN) {
     // the gates' range tests, on the box: a coordinate the periodic gate folds (c < lower or
     // c - lower >= width) leaves ix <= -1 or ix >= width - 1, one the mirror gate folds from
@@ -418,24 +356,22 @@ __device__ __forceinline__ void eu5_boxes(const eu_render_params &p, const eu4_p
       if (s.gate1 != 0 && full.mxy >= ch - 1) clean = false;
     }
   }
-  // passes: the tile at once, its halves or its quarters, whichever fits the slice first. The boxes of
-  // later passes are reduced again when their turn comes: two or four passes are the exception, and
-  // eight registers less live across the next tile's coordinate chain are worth more.
+  // passes: the tile at once, its halves or its quarters, whichever fits the slice first
   int npass = 1;
-  eu5_box b0 = full;
   const int f = eu5_box_fits<order>(full);
-  if (f < 0) npass = 0;
+  if (f < 0) npass = 0;                               // nothing hits: zeros
   else if (f == 0) {
-    npass = 2; b0 = half0;
-    if (eu5_box_fits<order>(half0) == 0 || eu5_box_fits<order>(half1) == 0) {
-      npass = 4; b0 = eu5_box_at(R.q0, R.q1, R.q2, R.q3, 15);
-      if (eu5_box_fits<order>(b0) == 0 || eu5_box_fits<order>(eu5_box_at(R.q0, R.q1, R.q2, R.q3, 31)) == 0 ||
-          eu5_box_fits<order>(eu5_box_at(R.q0, R.q1, R.q2, R.q3, 47)) == 0 || eu5_box_fits<order>(eu5_box_at(R.q0, R.q1, R.q2, R.q3, 63)) == 0)
+    npass = 2;
+    if (eu5_box_fits<order>(eu5_box_at(h0, h1, h2, h3, 31)) == 0 || eu5_box_fits<order>(eu5_box_at(h0, h1, h2, h3, 63)) == 0) {
+      npass = 4;
+      if (eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 15)) == 0 || eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 31)) == 0 ||
+          eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 47)) == 0 || eu5_box_fits<order>(eu5_box_at(q0, q1, q2, q3, 63)) == 0)
         npass = -1;
     }
   }
-  if (npass > 0 && !clean) npass = -1;
-  if (npass < 0) {
+  EU5_STAMP(3);
+  float *const orow = p.out + (long long)(yc - p.row_begin) * p.out_stride;
+  if (npass < 0 || (npass > 0 && !clean)) {
     // not even the quarters fit (the pole of a lat/lon source, the +-180 degree seam, strong
     // minification), or a hitting pixel left the fast path of the coordinate arithmetic: left to the
     // direct-gather kernel behind this one
@@ -445,19 +381,102 @@ __device__ __forceinline__ void eu5_boxes(const eu_render_params &p, const eu4_p
       const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
       p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
     }
+    return;
   }
-  B.npass = __builtin_amdgcn_readfirstlane(npass);
-  B.box0 = eu5_uniform(b0);
+  eu_f2 rga = { 0.0f, 0.0f }, bxa = { 0.0f, 0.0f }, rgb = { 0.0f, 0.0f }, bxb = { 0.0f, 0.0f };
+  if (npass > 0) {
+    const unsigned lds_tile = (unsigned)(unsigned long long)(eu4_lds_void)wtile;
+    const int grp = npass == 1 ? 0 : npass == 2 ? hf : (lane >> 4);
+#pragma unroll 1
+    for (int pi = 0; pi < npass; pi++) {
+      eu5_box bx = full;
+      if (npass > 1) {
+        // lane 31 / 63 of the halves' copies, lane 15 / 31 / 47 / 63 of the quarters
+        const int ln = npass == 2 ? 31 + 32 * pi : 15 + 16 * pi;
+        const eu5_box bh = eu5_box_at(h0, h1, h2, h3, ln), bq = eu5_box_at(q0, q1, q2, q3, ln);
+        bx = npass == 2 ? bh : bq;
+      }
+      if (bx.mnx == INT_MAX) continue;               // a half / quarter without a hitting pixel
+      const int ibw = bx.mxx - bx.mnx + order, ibh = bx.mxy - bx.mny + order;
+      {
+        // stage the box: lane L fetches the texel of box column L % ibw in row L / ibw of the k = 64 / ibw
+        // rows ONE LDS-DMA instruction covers (an LDS-DMA instruction costs its wave 60-180 cycles of issue
+        // whatever it moves: one per box row was 14-25 per tile); the LDS image is the box, rows back to back
+        const unsigned tv = eu5_divtab.v[ibw];
+        const int k = (int)(tv >> 24);
+        const unsigned r = ((unsigned)lane * (tv & 0x1ffffu)) >> 16, c = (unsigned)lane - r * (unsigned)ibw;
+        const int bx0 = bx.mnx - DEG / 2, by0 = bx.mny - DEG / 2;
+        const unsigned pitchb = (unsigned)(s.es1 * 4);
+        const unsigned voff = r * pitchb + c * (NCH * 4u);
+        const char *sb = (const char *)(s.base + ((long long)by0 * s.es1 + (long long)bx0 * NCH));
+        const unsigned long long step = (unsigned long long)k * pitchb;
+        unsigned dst = lds_tile;
+        const unsigned dstep = (unsigned)(k * ibw) * (TEX * 4u);
+        int left = ibh;
+        if ((int)r < k) {
+#pragma unroll 1
+          for (; left >= k; left -= k) { eu4_dma_row(dst, voff, sb); sb += step; dst += dstep; }
+        }
+        left = ibh % k;
+        if ((int)r < left) {
+          const int full = ibh / k;     // the loop above ran on other lanes only: recompute its end
+          eu4_dma_row(lds_tile + (unsigned)full * dstep, voff,
+                      (const char *)(s.base + ((long long)by0 * s.es1 + (long long)bx0 * NCH)) + (unsigned long long)full * step);
+        }
+      }
+      if (pi == 0) {
+        // the weights, behind the DMA issue
+        if constexpr (DEG >= 2) {
+          eu_weights2<DEG>(s.wm, ty, wy);
+          if constexpr (!HOIST) eu_weights2<DEG>(s.wm, tx, wx);
+        }
+      }
+      // lanes of other groups and lanes without a hit read the box origin
+      const bool mine = grp == pi;
+      const int oa = (mine && hit.x) ? ((iya - bx.mny) * ibw + (ixa - bx.mnx)) * TEX : 0;
+      const int ob = (mine && hit.y) ? ((iyb - bx.mny) * ibw + (ixb - bx.mnx)) * TEX : 0;
+      if (pi == 0) EU5_STAMP(4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (pi == 0) EU5_STAMP(5);
+      if (mine) eu5_taps<NCH, DEG>((eu_lptr)wtile, oa, ob, ibw * TEX, wx, wy, tx, ty, rga, bxa, rgb, bxb);
+    }
+  }
+#ifdef EU5_STAMPS
+  asm volatile("" : : "v"(rga), "v"(bxa), "v"(rgb), "v"(bxb));
+#endif
+  EU5_STAMP(6);
+  // environment::eval brighten (environment.h:1821-1842), zero on a miss; storer
+  float qa[4] = { rga.x, rga.y, bxa.x, bxa.y }, qb[4] = { rgb.x, rgb.y, bxb.x, bxb.y };
+  constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
+  const bool bright = !FAST && s.brighten != 1.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    float a = qa[c], bb = qb[c];
+    if (bright && c < ncol) { a = a * s.brighten; bb = bb * s.brighten; }
+    qa[c] = hit.x ? a : 0.0f;
+    qb[c] = hit.y ? bb : 0.0f;
+  }
+  if (va) eu_put<NCH>(orow, xa, qa);
+  if (vb) eu_put<NCH>(orow, xb, qb);
+  EU5_STAMP(7);
+#ifdef EU5_STAMPS
+  if (lane == 0 && w.stamps) {
+    unsigned long long *o = w.stamps + ((size_t)tile_y * w.tiles16 + x0 / EU4_TW) * 8;
+    st_[1] = (unsigned long long)(npass + 1) | (HOIST ? 16ull : 0ull);
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = st_[k];
+  }
+#endif
 }
 
-// stage a box: lane L fetches the texel of box column L % ibw in row L / ibw of the k = 64 / ibw rows
-// ONE LDS-DMA instruction covers (an LDS-DMA instruction costs its wave 60-180 cycles of issue whatever
-// it moves: one per box row was 14-25 per tile); the LDS image is the box, rows back to back
+
+
+// stage a box: lane L fetches the texel of box column L % ibw in row L / ibw of the k = 64 / ibw rows ONE
+// LDS-DMA instruction covers; the LDS image is the box, rows back to back
 template <int NCH, int DEG>
 __device__ __forceinline__ void eu5_stage(const eu_src_dev &s, const eu5_box &bx, unsigned lds_tile, int lane)
 {
   constexpr int order = DEG + 1;
-  if (bx.mnx == INT_MAX) return;
   const int ibw = bx.mxx - bx.mnx + order, ibh = bx.mxy - bx.mny + order;
   const unsigned tv = eu5_divtab.v[ibw];
   const int k = (int)(tv >> 24);
@@ -480,75 +499,130 @@ __device__ __forceinline__ void eu5_stage(const eu_src_dev &s, const eu5_box &bx
   }
 }
 
-// weights of the y axis, the taps of every pass, brighten, store
-template <int NCH, int DEG, bool HOIST, bool FAST>
-__device__ __forceinline__ void eu5_finish(const eu_render_params &p, const eu5_coord<DEG, HOIST> &C, const eu5_plan1 &B,
-                                           float *wtile, int tile_y, int x0, int lane)
+// A 16x16 tile on tile rows with a column plan (FAST profile, lat/lon source): FOUR pixels per lane - the
+// pairs (xa, xb) of rows y and y + 8. The two pairs share everything that depends on the column (the table
+// entry: base position, x weights, sqrt(rx^2 + rz^2)) and run two independent latitude chains, which is what a
+// wave needs to issue a packed operation every 4 cycles instead of every 8 (a dependent chain of packed
+// operations issues at half rate, and four waves per SIMD do not always have two of them in a vector phase);
+// the box reduction, the DMA issue and its round trip are paid once per 256 pixels. Headline: the box of a
+// 16x16 tile of an equatorial face is at most 24 x 24 texels - the slice. Returns false when the tile has to
+// be rendered as two 16x8 tiles (box too large, a lane off the fast path).
+template <int NCH, int DEG>
+__device__ __forceinline__ bool eu5_tile16h(const eu_render_params &p, const eu4_plan &w, const float *atab,
+                                            float *wtile, const float *ct, int tile_y, int x0, int lane)
 {
   constexpr int order = DEG + 1;
   const eu_src_dev &s = p.src;
-  const bool hita = C.flags & 1, hitb = C.flags & 2;
-  eu_f2 rga = { 0.0f, 0.0f }, bxa = { 0.0f, 0.0f }, rgb = { 0.0f, 0.0f }, bxb = { 0.0f, 0.0f };
-  if (B.npass > 0) {
-    eu_f2 wy[order], wx[order];
-    if constexpr (DEG >= 2) {
-      eu_weights2<DEG>(s.wm, C.ty, wy);
-      if constexpr (HOIST) {
-#pragma unroll
-        for (int i = 0; i < order; i++) wx[i] = C.wx[i];
-      } else eu_weights2<DEG>(s.wm, C.wx[0], wx);
-    }
-    const unsigned lds_tile = (unsigned)(unsigned long long)(eu4_lds_void)wtile;
-    const int grp = B.npass == 1 ? 0 : B.npass == 2 ? (lane >> 5) : (lane >> 4);
-    eu5_box bx = B.box0;                              // pass 0: staged before the next tile's coordinates
-#pragma unroll 1
-    for (int pi = 0; pi < B.npass; pi++) {
-      if (pi > 0) {
-        // lane 63 of the halves' copies, lane 31 / 47 / 63 of the quarters
-        eu5_red R;
-        eu5_reduce<DEG, HOIST>(C, R);
-        const int ln = B.npass == 2 ? 63 : 15 + 16 * pi;
-        const eu5_box bh = eu5_box_at(R.h0, R.h1, R.h2, R.h3, ln), bq = eu5_box_at(R.q0, R.q1, R.q2, R.q3, ln);
-        bx = eu5_uniform(B.npass == 2 ? bh : bq);
-        eu5_stage<NCH, DEG>(s, bx, lds_tile, lane);
-      }
-      if (bx.mnx == INT_MAX) continue;               // a half / quarter without a hitting pixel
-      const int ibw = bx.mxx - bx.mnx + order;
-      // lanes of other groups and lanes without a hit read the box origin
-      const bool mine = grp == pi;
-      const int oa = (mine && hita) ? ((C.iya - bx.mny) * ibw + (C.ixa - bx.mnx)) * 4 : 0;
-      const int ob = (mine && hitb) ? ((C.iyb - bx.mny) * ibw + (C.ixb - bx.mnx)) * 4 : 0;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (mine) eu5_taps<NCH, DEG>((eu_lptr)wtile, oa, ob, ibw * 4, wx, wy, C.wx[0], C.ty, rga, bxa, rgb, bxb);
-    }
+  const int pr = lane & 3, rw = (lane >> 2) & 7, hf = lane >> 5;
+  const int yA = p.row_begin + tile_y * EU4_TH + rw, yB = yA + EU4_TH;
+  const bool yinA = yA < p.row_end, yinB = yB < p.row_end;
+  const int ycA = yinA ? yA : p.row_end - 1, ycB = yinB ? yB : p.row_end - 1;
+  const float *rtA = p.row + (long long)ycA * EU_ROW_FLOATS, *rtB = p.row + (long long)ycB * EU_ROW_FLOATS;
+  const int xa = x0 + 8 * hf + 2 * pr, xb = xa + 1;
+  const bool vxa = xa < p.width, vxb = xb < p.width;
+  const int xac = vxa ? xa : p.width - 1, xbc = vxb ? xb : p.width - 1;
+  const eu4_f4 *ea = (const eu4_f4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
+  const eu4_f4 *eb = (const eu4_f4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
+  const eu4_f4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
+  const float A1A = rtA[1], B1A = rtA[4], A1B = rtB[1], B1B = rtB[4];
+  const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+  const eu_f2 ryA = B1A * c0 + A1A, ryB = B1B * c0 + A1B;
+  const int ixa = __float_as_int(a0.x), ixb = __float_as_int(b0.x);
+  eu_f2 wx[order];
+  const eu_f2 tx = { a0.y, b0.y };
+  if constexpr (DEG >= 2) {
+    wx[0] = (eu_f2){ a0.z, b0.z }; wx[1] = (eu_f2){ a0.w, b0.w }; wx[2] = (eu_f2){ a1.x, b1.x };
+    if constexpr (DEG == 3) wx[3] = (eu_f2){ a1.y, b1.y };
   }
-  // environment::eval brighten (environment.h:1821-1842), zero on a miss; storer
-  float qa[4] = { rga.x, rga.y, bxa.x, bxa.y }, qb[4] = { rgb.x, rgb.y, bxb.x, bxb.y };
-  constexpr int ncol = (NCH == 2 || NCH == 4) ? NCH - 1 : NCH;
-  const bool bright = !FAST && s.brighten != 1.0f;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    float a = qa[c], bb = qb[c];
-    if (bright && c < ncol) { a = a * s.brighten; bb = bb * s.brighten; }
-    qa[c] = hita ? a : 0.0f;
-    qb[c] = hitb ? bb : 0.0f;
+  const eu_f2 qs = { a1.z, b1.z };
+  eu_i2 bigA = { 0, 0 }, bigB = { 0, 0 };
+  // a lane is off the fast path when a column entry is, or an operand leaves the range of the FMA sequences
+  int bad = ((ixa != INT_MIN && ixb != INT_MIN) ? 0 : -1) |
+            eu5_out_of_range3(ryA.x, qs.x, ryB.x) | eu5_out_of_range3(ryA.y, qs.y, ryB.y);
+  const eu_f2 latA = eu_atan2f_2_lean(ryA, qs, atab, 1, bigA);
+  const eu_f2 latB = eu_atan2f_2_lean(ryB, qs, atab, 1, bigB);
+  bad |= bigA.x | bigA.y | bigB.x | bigB.y;
+  // source_t::md_to_spline, y (environment.h:988-1006)
+  const float rr = s.cdiv_ok ? 0.0f : eu_rcp_refined(s.ext_h);
+  eu_f2 iA = { (float)((double)latA.x - s.tex_y0), (float)((double)latA.y - s.tex_y0) };
+  eu_f2 iB = { (float)((double)latB.x - s.tex_y0), (float)((double)latB.y - s.tex_y0) };
+  if (s.cdiv_ok) { iA = eu_div2_const(iA, s.ext_h, s.rcp_ext_h); iB = eu_div2_const(iB, s.ext_h, s.rcp_ext_h); }
+  else { iA = eu_div2_rr(iA, s.ext_h, rr); iB = eu_div2_rr(iB, s.ext_h, rr); }
+  iA = iA * s.total_h; iA = iA - .5f; iB = iB * s.total_h; iB = iB - .5f;
+  const eu_f2 gyA = eu5_gate2(iA - s.win_y_off, s.gate1, s.lower1, s.upper1);
+  const eu_f2 gyB = eu5_gate2(iB - s.win_y_off, s.gate1, s.lower1, s.upper1);
+  eu_f2 fyA, fyB;
+  if constexpr (DEG & 1) { fyA = (eu_f2){ floorf(gyA.x), floorf(gyA.y) }; fyB = (eu_f2){ floorf(gyB.x), floorf(gyB.y) }; }
+  else { fyA = (eu_f2){ roundf(gyA.x), roundf(gyA.y) }; fyB = (eu_f2){ roundf(gyB.x), roundf(gyB.y) }; }
+  const eu_f2 tyA = gyA - fyA, tyB = gyB - fyB;
+  const int iyAa = (int)fyA.x, iyAb = (int)fyA.y, iyBa = (int)fyB.x, iyBb = (int)fyB.y;
+  // every ray hits (FAST): a pixel counts when it lies inside the frame
+  const bool hAa = yinA && vxa, hAb = yinA && vxb, hBa = yinB && vxa, hBb = yinB && vxb;
+
+  // the tile's box
+  int q0 = INT_MAX, q1 = INT_MAX, q2 = INT_MIN, q3 = INT_MIN, h0, h1, h2, h3;
+  if (hAa) { q0 = ixa; q2 = ixa; q1 = iyAa; q3 = iyAa; }
+  if (hAb) { q0 = min(q0, ixb); q2 = max(q2, ixb); q1 = min(q1, iyAb); q3 = max(q3, iyAb); }
+  if (hBa) { q0 = min(q0, ixa); q2 = max(q2, ixa); q1 = min(q1, iyBa); q3 = max(q3, iyBa); }
+  if (hBb) { q0 = min(q0, ixb); q2 = max(q2, ixb); q1 = min(q1, iyBb); q3 = max(q3, iyBb); }
+  eu5_box_reduce(q0, q1, q2, q3, h0, h1, h2, h3);
+  eu5_box bx = eu5_box_join(eu5_box_at(h0, h1, h2, h3, 31), eu5_box_at(h0, h1, h2, h3, 63));
+  bool fast = __ballot(bad != 0 && (hAa || hAb || hBa || hBb)) == 0ull;
+  if (bx.mnx == INT_MAX) return true;                        // nothing inside the frame
+  {
+    const int cw = (int)(s.upper0 + 0.5f), ch = (int)(s.upper1 + 0.5f);
+    if (s.gate0 == 2 && bx.mnx < 0) fast = false;
+    if (s.gate0 != 0 && bx.mxx >= cw - 1) fast = false;
+    if (s.gate1 == 2 && bx.mny < 0) fast = false;
+    if (s.gate1 != 0 && bx.mxy >= ch - 1) fast = false;
   }
-  // pixels inside the frame (a row that is, is below row_end): [half | row | pair]
-  const int xa = x0 + 8 * (lane >> 5) + 2 * (lane & 3), yl = tile_y * EU4_TH + ((lane >> 2) & 7);
-  float *const orow = p.out + (long long)yl * p.out_stride;
-  if (C.flags & 8) eu_put<NCH>(orow, xa, qa);
-  if (C.flags & 16) eu_put<NCH>(orow, xa + 1, qb);
+  if (!fast || eu5_box_fits<order>(bx) != 1) return false;
+  bx.mnx = __builtin_amdgcn_readfirstlane(bx.mnx); bx.mny = __builtin_amdgcn_readfirstlane(bx.mny);
+  bx.mxx = __builtin_amdgcn_readfirstlane(bx.mxx); bx.mxy = __builtin_amdgcn_readfirstlane(bx.mxy);
+  const unsigned lds_tile = (unsigned)(unsigned long long)(eu4_lds_void)wtile;
+  eu5_stage<NCH, DEG>(s, bx, lds_tile, lane);
+  // the y weights of both pairs, behind the DMA issue
+  eu_f2 wyA[order], wyB[order];
+  if constexpr (DEG >= 2) { eu_weights2<DEG>(s.wm, tyA, wyA); eu_weights2<DEG>(s.wm, tyB, wyB); }
+  const int ibw = bx.mxx - bx.mnx + order;
+  const int oAa = hAa ? ((iyAa - bx.mny) * ibw + (ixa - bx.mnx)) * 4 : 0, oAb = hAb ? ((iyAb - bx.mny) * ibw + (ixb - bx.mnx)) * 4 : 0;
+  const int oBa = hBa ? ((iyBa - bx.mny) * ibw + (ixa - bx.mnx)) * 4 : 0, oBb = hBb ? ((iyBb - bx.mny) * ibw + (ixb - bx.mnx)) * 4 : 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  eu_f2 rga, bxa, rgb, bxb;
+  eu5_taps<NCH, DEG>((eu_lptr)wtile, oAa, oAb, ibw * 4, wx, wyA, tx, tyA, rga, bxa, rgb, bxb);
+  // (the sums are complete here, whatever the stores' conditions: keeps the evaluation out of the
+  // conditional blocks and the window reads 16 bytes wide)
+  asm volatile("" : "+v"(rga), "+v"(bxa), "+v"(rgb), "+v"(bxb));
+  {
+    float qa[4] = { rga.x, rga.y, bxa.x, bxa.y }, qb[4] = { rgb.x, rgb.y, bxb.x, bxb.y };
+    float *const orow = p.out + (long long)(ycA - p.row_begin) * p.out_stride;
+    if (hAa) eu_put<NCH>(orow, xa, qa);
+    if (hAb) eu_put<NCH>(orow, xb, qb);
+  }
+  // one pair after the other: interleaved, the two sets of windows do not fit the registers
+  __builtin_amdgcn_sched_barrier(0);
+  eu5_taps<NCH, DEG>((eu_lptr)wtile, oBa, oBb, ibw * 4, wx, wyB, tx, tyB, rga, bxa, rgb, bxb);
+  asm volatile("" : "+v"(rga), "+v"(bxa), "+v"(rgb), "+v"(bxb));
+  {
+    float qa[4] = { rga.x, rga.y, bxa.x, bxa.y }, qb[4] = { rgb.x, rgb.y, bxb.x, bxb.y };
+    float *const orow = p.out + (long long)(ycB - p.row_begin) * p.out_stride;
+    if (hBa) eu_put<NCH>(orow, xa, qa);
+    if (hBb) eu_put<NCH>(orow, xb, qb);
+  }
+  return true;
 }
 
-// the tiles of one wave: XCD x owns the units x, x + 8, ... of EU5_UNIT_ROWS tile rows; its K waves walk
-// that list in raster order, wave k taking tiles k, k + K, ...
+// the tiles of one wave: XCD x owns the units x, x + 8, ... of UNIT tile rows (of RPT 16x8 tile rows each);
+// its K waves walk that list in raster order, wave k taking tiles k, k + K, ...
+template <int UNIT>
 struct eu5_iter {
   int ul, ry, rx;             // local unit, tile row inside the unit, tile column
   int du, dy, dx;             // the step of K tiles in the same terms
-  int xcd, units, tiles16, tiles_y;
+  int xcd, units, tiles16;
   __device__ __forceinline__ void start(int t0, int K)
   {
-    const int per_unit = EU5_UNIT_ROWS * tiles16;
+    const int per_unit = UNIT * tiles16;
     ul = t0 / per_unit;
     ry = (t0 - ul * per_unit) / tiles16;
     rx = t0 - ul * per_unit - ry * tiles16;
@@ -558,72 +632,18 @@ struct eu5_iter {
   {
     rx += dx; ry += dy; ul += du;
     if (rx >= tiles16) { rx -= tiles16; ry++; }
-    if (ry >= EU5_UNIT_ROWS) { ry -= EU5_UNIT_ROWS; ul++; }
+    if (ry >= UNIT) { ry -= UNIT; ul++; }
   }
-  // moves on to the next tile inside the frame whose tile row has (want_plan) / has not a column plan;
-  // false when the list is exhausted. plan_out: the plan of the tile row, -1: none
-  __device__ __forceinline__ bool settle(const int *tileplan, bool want_plan, int &plan_out)
-  {
-    while (true) {
-      if (ul * 8 + xcd >= units) return false;
-      const int ty = (ul * 8 + xcd) * EU5_UNIT_ROWS + ry;
-      if (ty < tiles_y) {
-        plan_out = tileplan ? tileplan[ty] : -1;
-        if ((plan_out >= 0) == want_plan) return true;
-      }
-      step();
-    }
-  }
-  __device__ __forceinline__ int tile_y() const { return (ul * 8 + xcd) * EU5_UNIT_ROWS + ry; }
+  __device__ __forceinline__ bool done() const { return ul * 8 + xcd >= units; }
+  __device__ __forceinline__ int row() const { return (ul * 8 + xcd) * UNIT + ry; }
 };
 
-// one skewed loop over the wave's tiles with (HOIST) / without a column plan: kept apart so that each gets
-// a register allocation of its own (together they spill)
-template <int NCH, int DEG, int PRJ, bool HOIST, bool FAST>
-__device__ __forceinline__ void eu5_loop(const eu_render_params &p, const eu4_plan &w, const float *atab, float *tile,
-                                         int lane0, int wave)
+// tile rows 2m and 2m + 1 form a 16x16 row of the first loop when both have the same column plan
+__device__ __forceinline__ int eu5_pair_plan(const int *tileplan, int tiles_y, int m)
 {
-  constexpr bool LEAN = FAST && PRJ == EU_SPHERICAL;
-  const int *const tileplan = PRJ == EU_SPHERICAL ? w.tileplan : nullptr;
-  // blocks are dealt round-robin to the 8 XCDs: blockIdx.x & 7 names the XCD (up to a rotation; for speed only)
-  eu5_iter it;
-  it.xcd = (int)(blockIdx.x & 7);
-  it.tiles16 = w.tiles16; it.tiles_y = p.tiles_y;
-  it.units = (p.tiles_y + EU5_UNIT_ROWS - 1) / EU5_UNIT_ROWS;
-  it.start((int)(blockIdx.x >> 3) * EU5_WAVES + wave, (int)(gridDim.x >> 3) * EU5_WAVES);
-
-  eu5_loaded Ln;
-  eu5_coord<DEG, HOIST> Cn, Cc;
-  eu5_plan1 Bc;
-  int ty_n = 0, x0_n = 0, plan_n = -1, ty_c = 0, x0_c = 0;
-  bool have_c = false, have_n = it.settle(tileplan, HOIST, plan_n);
-  if (have_n) {
-    ty_n = it.tile_y(); x0_n = it.rx * EU4_TW;
-    eu5_load<HOIST, FAST>(p, HOIST ? w.coltab + (size_t)plan_n * p.width * EU4_COL_FLOATS : nullptr, ty_n, x0_n, lane0, Ln);
-  }
-#pragma unroll 1
-  while (have_c || have_n) {
-    // everything a stage derives from the lane index is recomputed per stage (kept live across the
-    // loop it costs registers the tile code needs)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const unsigned lds_tile = (unsigned)(unsigned long long)(eu4_lds_void)tile;
-    if (have_c) eu5_boxes<DEG, HOIST, LEAN>(p, w, Cc, ty_c, x0_c, lane, Bc);
-    if (have_n) eu5_settle(Ln);
-    if (have_c && Bc.npass > 0) eu5_stage<NCH, DEG>(p.src, Bc.box0, lds_tile, lane);
-    if (have_n) eu5_coords<NCH, DEG, PRJ, HOIST, FAST>(p, atab, Ln, ty_n, x0_n, lane, Cn);
-    if (have_c && Bc.npass >= 0) eu5_finish<NCH, DEG, HOIST, FAST>(p, Cc, Bc, tile, ty_c, x0_c, lane);
-    // rotate: the next tile becomes the current one; the loads of the tile after it go out
-    Cc = Cn; ty_c = ty_n; x0_c = x0_n; have_c = have_n;
-    if (have_n) {
-      it.step();
-      have_n = it.settle(tileplan, HOIST, plan_n);
-      if (have_n) {
-        ty_n = it.tile_y(); x0_n = it.rx * EU4_TW;
-        eu5_load<HOIST, FAST>(p, HOIST ? w.coltab + (size_t)plan_n * p.width * EU4_COL_FLOATS : nullptr, ty_n, x0_n, lane, Ln);
-      }
-    }
-  }
+  if (2 * m + 1 >= tiles_y) return -1;
+  const int a = tileplan[2 * m], b = tileplan[2 * m + 1];
+  return a == b ? a : -1;
 }
 
 // grid: 8 * (workgroups per XCD); the launcher sizes it to what is resident at once
@@ -643,9 +663,60 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  // the tile rows with a column plan (upright cubemap / rectilinear targets of a lat/lon source: the x half
-  // of the coordinates is a function of the column), then the others
-  if constexpr (PRJ == EU_SPHERICAL) eu5_loop<NCH, DEG, PRJ, true, FAST>(p, w, atab, tile, lane0, wave);
-  eu5_loop<NCH, DEG, PRJ, false, FAST>(p, w, atab, tile, lane0, wave);
+  // blocks are dealt round-robin to the 8 XCDs: blockIdx.x & 7 names the XCD (up to a rotation;
+  // for speed only)
+  const int xcd = (int)(blockIdx.x & 7);
+  const int K = (int)(gridDim.x >> 3) * EU5_WAVES;
+  const int t0 = (int)(blockIdx.x >> 3) * EU5_WAVES + wave;
+  constexpr bool PAIRS = FAST && PRJ == EU_SPHERICAL;
+  if constexpr (PAIRS) {
+    // first the pairs of tile rows with a common column plan, as 16x16 tiles
+    eu5_iter<EU5_UNIT_ROWS / 2> it;
+    it.xcd = xcd; it.tiles16 = w.tiles16;
+    const int rows2 = (p.tiles_y + 1) / 2;
+    it.units = (rows2 + EU5_UNIT_ROWS / 2 - 1) / (EU5_UNIT_ROWS / 2);
+    it.start(t0, K);
+#pragma unroll 1
+    for (; !it.done(); it.step()) {
+      const int m = it.row();
+      if (m >= rows2) continue;
+      const int plan = eu5_pair_plan(w.tileplan, p.tiles_y, m);
+      if (plan < 0) continue;
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const float *ct = w.coltab + (size_t)plan * p.width * EU4_COL_FLOATS;
+      if (!eu5_tile16h<NCH, DEG>(p, w, atab, tile, ct, 2 * m, it.rx * EU4_TW, lane)) {
+        // both 16x8 tiles to the direct-gather kernel (a rare event: the +-180 degree seam, a box beyond the slice)
+        if (lane < 2) {
+          const int id = (2 * m + lane) * w.tiles16 + it.rx;
+          const int sh = eu4_shard_of(id);
+          const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
+          p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
+        }
+      }
+    }
+  }
+  // XCD x owns the units x, x + 8, ... of EU5_UNIT_ROWS tile rows; its waves walk that list in raster
+  // order, wave k taking tiles k, k + K, ...
+  eu5_iter<EU5_UNIT_ROWS> it;
+  it.xcd = xcd; it.tiles16 = w.tiles16;
+  it.units = (p.tiles_y + EU5_UNIT_ROWS - 1) / EU5_UNIT_ROWS;
+  it.start(t0, K);
+#pragma unroll 1
+  for (; !it.done(); it.step()) {
+    const int tile_y = it.row();
+    if (tile_y >= p.tiles_y) continue;
+    if (PAIRS && eu5_pair_plan(w.tileplan, p.tiles_y, tile_y >> 1) >= 0) continue;   // rendered by the first loop
+    // everything a tile derives from the lane index is recomputed per tile (kept live across the
+    // loop it costs registers the tile code needs)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int plan = PRJ == EU_SPHERICAL ? w.tileplan[tile_y] : -1;
+    if (plan >= 0)
+      eu5_tile<NCH, DEG, PRJ, PRJ == EU_SPHERICAL, FAST>(p, w, atab, tile, w.coltab + (size_t)plan * p.width * EU4_COL_FLOATS,
+                                                          tile_y, it.rx * EU4_TW, lane);
+    else
+      eu5_tile<NCH, DEG, PRJ, false, FAST>(p, w, atab, tile, nullptr, tile_y, it.rx * EU4_TW, lane);
+  }
 }
 
