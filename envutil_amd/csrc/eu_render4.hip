@@ -784,7 +784,8 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
 #ifdef EU5_STAMPS
   // diagnostic build: stamps of every tile, averaged per pass count / plan kind after the launch
   static unsigned long long *d_st = nullptr; static size_t st_cap = 0; static int dumps = 0;
-  const size_t nst = (size_t)w.tiles16 * p.tiles_y * 8;
+  const size_t ntile_st = (size_t)w.tiles16 * p.tiles_y * 8;
+  const size_t nst = ntile_st + 8192 * 4;      // + per-wave totals (eu_render5_kernel)
   if (st_cap < nst) { if (d_st) (void)hipFree(d_st); if (hipMalloc((void **)&d_st, nst * 8) != hipSuccess) return -1; st_cap = nst; }
   (void)hipMemsetAsync(d_st, 0, nst * 8, st);
   w.stamps = d_st;
@@ -795,7 +796,7 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(h.data(), d_st, nst * 8, hipMemcpyDeviceToHost);
     double acc[32][8] = {}; size_t cnt[32] = {};
-    for (size_t t = 0; t < nst / 8; t++) {
+    for (size_t t = 0; t < ntile_st / 8; t++) {
       const unsigned long long *q = &h[t * 8];
       if (!q[0] || !q[7]) continue;
       const int cls = (int)(q[1] & 31);
@@ -803,6 +804,18 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
       acc[cls][0] += (double)(q[2] - q[0]); acc[cls][1] += (double)(q[3] - q[2]);
       if (q[4]) { acc[cls][2] += (double)(q[4] - q[3]); acc[cls][3] += (double)(q[5] - q[4]); acc[cls][4] += (double)(q[6] - q[5]); }
       acc[cls][5] += (double)(q[7] - q[6]); acc[cls][6] += (double)(q[7] - q[0]);
+    }
+    {
+      double mn = 1e30, mx = 0, sum = 0, l1 = 0, first = 1e30, last = 0; size_t nw = 0;
+      for (size_t k = 0; k < 8192; k++) {
+        const unsigned long long *q = &h[ntile_st + k * 4];
+        if (!q[3]) continue;
+        const double d = (double)(q[2] - q[0]);
+        mn = std::min(mn, d); mx = std::max(mx, d); sum += d; l1 += (double)(q[1] - q[0]); nw++;
+        first = std::min(first, (double)q[0]); last = std::max(last, (double)q[2]);
+      }
+      if (nw) fprintf(stderr, "eu5 waves: %zu, cycles per wave min %.0f avg %.0f max %.0f, first loop avg %.0f, first start .. last end %.0f\n",
+                      nw, mn, sum / nw, mx, l1 / nw, last - first);
     }
     for (int c = 0; c < 32; c++) if (cnt[c])
       fprintf(stderr, "eu5 stamps: hoist %d npass %2d tiles %8zu | coords %7.0f box %6.0f dma-issue+weights %6.0f dma-wait %6.0f taps(all passes) %6.0f store %5.0f | tile %7.0f (100 MHz ticks? s_memtime)\n",

@@ -189,10 +189,31 @@ __device__ __forceinline__ int eu5_out_of_range3(float a, float b, float c)
 // normalisation, no bands, every ray hits, the verified constant division, brighten 1 (what a
 // cubemap / rectilinear target of a full-sphere or cubemap source is). The persistent loop keeps
 // every scalar it uses live: fewer of them means no SGPR spills in the tile code.
-template <int NCH, int DEG, int PRJ, bool HOIST, bool FAST>
-__device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_plan &w, const float *atab,
-                                         float *wtile, const float *ct, int tile_y, int x0, int lane)
+// what a 16x8 tile without a column plan reads from the stepper tables (FAST profile: 'B * c0 + A')
+struct eu5_tab8 { eu_f2 c0; float A0, A1, A2, B0, B1, B2; };
+
+template <bool FAST>
+__device__ __forceinline__ void eu5_load8(const eu_render_params &p, int tile_y, int x0, int lane, eu5_tab8 &T)
 {
+  const int pr = lane & 3, rw = (lane >> 2) & 7, hf = lane >> 5;
+  const int y = p.row_begin + tile_y * EU4_TH + rw;
+  const int yc = y < p.row_end ? y : p.row_end - 1;
+  const float *rt = p.row + (long long)(FAST ? yc : eu_frame_row(yc, p.band_shift, p.band_count, p.band_index)) * EU_ROW_FLOATS;
+  const int xa = x0 + 8 * hf + 2 * pr, xb = xa + 1;
+  const int xac = xa < p.width ? xa : p.width - 1, xbc = xb < p.width ? xb : p.width - 1;
+  T.A0 = rt[0]; T.A1 = rt[1]; T.A2 = rt[2]; T.B0 = rt[3]; T.B1 = rt[4]; T.B2 = rt[5];
+  T.c0 = (eu_f2){ p.col[xac], p.col[xbc] };
+}
+
+// PRE (with !HOIST, FAST): the tile's table values come in T, requested by the previous tile ahead of its
+// stores, and this tile requests the next one's (have_n, ty_n, x0_n -> Tn) ahead of its own - see eu5_tile16h
+template <int NCH, int DEG, int PRJ, bool HOIST, bool FAST, bool PRE = false>
+__device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_plan &w, const float *atab,
+                                         float *wtile, const float *ct, int tile_y, int x0, int lane,
+                                         const eu5_tab8 *T = nullptr, bool have_n = false, int ty_n = 0, int x0_n = 0,
+                                         eu5_tab8 *Tn = nullptr)
+{
+  static_assert(!PRE || (!HOIST && FAST), "the prefetching form exists for plain FAST tiles");
   constexpr int TEX = 4;
   constexpr int order = DEG + 1;
   const eu_src_dev &s = p.src;
@@ -238,8 +259,13 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
                     (ixb != INT_MIN ? -1 : 0) & ~eu5_out_of_range3(ryy.y, qs.y, qs.y) };
       lat = eu_atan2f_2_lean(ryy, qs, atab, 1, big0);
     } else {
-      const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
-      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      float A0, A1, A2, B0, B1, B2;
+      eu_f2 c0;
+      if constexpr (PRE) { A0 = T->A0; A1 = T->A1; A2 = T->A2; B0 = T->B0; B1 = T->B1; B2 = T->B2; c0 = T->c0; }
+      else {
+        A0 = rt[0]; A1 = rt[1]; A2 = rt[2]; B0 = rt[3]; B1 = rt[4]; B2 = rt[5];
+        c0 = (eu_f2){ p.col[xac], p.col[xbc] };
+      }
       const eu_f2 rx = B0 * c0 + A0, ry = B1 * c0 + A1, rz = B2 * c0 + A2;
       ok = (eu_i2){ ~eu5_out_of_range3(rx.x, ry.x, rz.x), ~eu5_out_of_range3(rx.y, ry.y, rz.y) };
       const eu_f2 q2 = rx * rx + rz * rz;
@@ -295,8 +321,13 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
   } else {
     eu_ray2 r;
     {
-      const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
-      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+      float A0, A1, A2, B0, B1, B2;
+      eu_f2 c0;
+      if constexpr (PRE) { A0 = T->A0; A1 = T->A1; A2 = T->A2; B0 = T->B0; B1 = T->B1; B2 = T->B2; c0 = T->c0; }
+      else {
+        A0 = rt[0]; A1 = rt[1]; A2 = rt[2]; B0 = rt[3]; B1 = rt[4]; B2 = rt[5];
+        c0 = (eu_f2){ p.col[xac], p.col[xbc] };
+      }
       if (!FAST && p.form == EU_FORM_BCA) {
         const float C0 = rt[6], C1 = rt[7], C2 = rt[8];
         const float *colB = p.col + p.width;
@@ -381,6 +412,7 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
       const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
       p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
     }
+    if constexpr (PRE) { if (have_n) eu5_load8<FAST>(p, ty_n, x0_n, lane, *Tn); }
     return;
   }
   eu_f2 rga = { 0.0f, 0.0f }, bxa = { 0.0f, 0.0f }, rgb = { 0.0f, 0.0f }, bxb = { 0.0f, 0.0f };
@@ -456,6 +488,10 @@ __device__ __forceinline__ void eu5_tile(const eu_render_params &p, const eu4_pl
     qa[c] = hit.x ? a : 0.0f;
     qb[c] = hit.y ? bb : 0.0f;
   }
+  if constexpr (PRE) {
+    if (have_n) eu5_load8<FAST>(p, ty_n, x0_n, lane, *Tn);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (va) eu_put<NCH>(orow, xa, qa);
   if (vb) eu_put<NCH>(orow, xb, qb);
   EU5_STAMP(7);
@@ -507,26 +543,52 @@ __device__ __forceinline__ void eu5_stage(const eu_src_dev &s, const eu5_box &bx
 // the box reduction, the DMA issue and its round trip are paid once per 256 pixels. Headline: the box of a
 // 16x16 tile of an equatorial face is at most 24 x 24 texels - the slice. Returns false when the tile has to
 // be rendered as two 16x8 tiles (box too large, a lane off the fast path).
+// what a 16x16 tile reads from the stepper tables and the column table (22 registers)
+struct eu5_tab16 {
+  eu4_f4 a0, a1, b0, b1;      // the column entries of the lane's two columns
+  eu_f2 c0;                   // column table of the stepper
+  float A1A, B1A, A1B, B1B;   // row constants of the lane's two rows
+};
+
+__device__ __forceinline__ void eu5_load16(const eu_render_params &p, const float *ct, int tile_y, int x0, int lane, eu5_tab16 &T)
+{
+  const int pr = lane & 3, rw = (lane >> 2) & 7, hf = lane >> 5;
+  const int yA = p.row_begin + tile_y * EU4_TH + rw, yB = yA + EU4_TH;
+  const int ycA = yA < p.row_end ? yA : p.row_end - 1, ycB = yB < p.row_end ? yB : p.row_end - 1;
+  const float *rtA = p.row + (long long)ycA * EU_ROW_FLOATS, *rtB = p.row + (long long)ycB * EU_ROW_FLOATS;
+  const int xa = x0 + 8 * hf + 2 * pr, xb = xa + 1;
+  const int xac = xa < p.width ? xa : p.width - 1, xbc = xb < p.width ? xb : p.width - 1;
+  const eu4_f4 *ea = (const eu4_f4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
+  const eu4_f4 *eb = (const eu4_f4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
+  T.a0 = ea[0]; T.a1 = ea[1]; T.b0 = eb[0]; T.b1 = eb[1];
+  T.A1A = rtA[1]; T.B1A = rtA[4]; T.A1B = rtB[1]; T.B1B = rtB[4];
+  T.c0 = (eu_f2){ p.col[xac], p.col[xbc] };
+}
+
+// T: the tile's table values, requested by the PREVIOUS tile ahead of its stores; this tile does the same
+// for the next one (have_n, ct_n, ty_n, x0_n -> Tn). vmcnt counts in issue order: loads requested behind
+// a tile's stores cannot be waited for without waiting for the stores' acknowledgement too (1-2k cycles
+// at the head of every tile).
 template <int NCH, int DEG>
 __device__ __forceinline__ bool eu5_tile16h(const eu_render_params &p, const eu4_plan &w, const float *atab,
-                                            float *wtile, const float *ct, int tile_y, int x0, int lane)
+                                            float *wtile, const eu5_tab16 &T, int tile_y, int x0, int lane,
+                                            bool have_n, const float *ct_n, int ty_n, int x0_n, eu5_tab16 &Tn)
 {
   constexpr int order = DEG + 1;
   const eu_src_dev &s = p.src;
+#ifdef EU5_STAMPS
+  unsigned long long st_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+  EU5_STAMP(0);
   const int pr = lane & 3, rw = (lane >> 2) & 7, hf = lane >> 5;
   const int yA = p.row_begin + tile_y * EU4_TH + rw, yB = yA + EU4_TH;
   const bool yinA = yA < p.row_end, yinB = yB < p.row_end;
   const int ycA = yinA ? yA : p.row_end - 1, ycB = yinB ? yB : p.row_end - 1;
-  const float *rtA = p.row + (long long)ycA * EU_ROW_FLOATS, *rtB = p.row + (long long)ycB * EU_ROW_FLOATS;
   const int xa = x0 + 8 * hf + 2 * pr, xb = xa + 1;
   const bool vxa = xa < p.width, vxb = xb < p.width;
-  const int xac = vxa ? xa : p.width - 1, xbc = vxb ? xb : p.width - 1;
-  const eu4_f4 *ea = (const eu4_f4 *)(ct + (size_t)xac * EU4_COL_FLOATS);
-  const eu4_f4 *eb = (const eu4_f4 *)(ct + (size_t)xbc * EU4_COL_FLOATS);
-  const eu4_f4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
-  const float A1A = rtA[1], B1A = rtA[4], A1B = rtB[1], B1B = rtB[4];
-  const eu_f2 c0 = { p.col[xac], p.col[xbc] };
-  const eu_f2 ryA = B1A * c0 + A1A, ryB = B1B * c0 + A1B;
+  const eu4_f4 a0 = T.a0, a1 = T.a1, b0 = T.b0, b1 = T.b1;
+  const eu_f2 c0 = T.c0;
+  const eu_f2 ryA = T.B1A * c0 + T.A1A, ryB = T.B1B * c0 + T.A1B;
   const int ixa = __float_as_int(a0.x), ixb = __float_as_int(b0.x);
   eu_f2 wx[order];
   const eu_f2 tx = { a0.y, b0.y };
@@ -559,6 +621,10 @@ __device__ __forceinline__ bool eu5_tile16h(const eu_render_params &p, const eu4
   // every ray hits (FAST): a pixel counts when it lies inside the frame
   const bool hAa = yinA && vxa, hAb = yinA && vxb, hBa = yinB && vxa, hBb = yinB && vxb;
 
+#ifdef EU5_STAMPS
+  asm volatile("" : : "v"(iyAa), "v"(iyAb), "v"(iyBa), "v"(iyBb));
+#endif
+  EU5_STAMP(2);
   // the tile's box
   int q0 = INT_MAX, q1 = INT_MAX, q2 = INT_MIN, q3 = INT_MIN, h0, h1, h2, h3;
   if (hAa) { q0 = ixa; q2 = ixa; q1 = iyAa; q3 = iyAa; }
@@ -568,18 +634,22 @@ __device__ __forceinline__ bool eu5_tile16h(const eu_render_params &p, const eu4
   eu5_box_reduce(q0, q1, q2, q3, h0, h1, h2, h3);
   eu5_box bx = eu5_box_join(eu5_box_at(h0, h1, h2, h3, 31), eu5_box_at(h0, h1, h2, h3, 63));
   bool fast = __ballot(bad != 0 && (hAa || hAb || hBa || hBb)) == 0ull;
-  if (bx.mnx == INT_MAX) return true;                        // nothing inside the frame
-  {
+  if (bx.mnx != INT_MAX) {
     const int cw = (int)(s.upper0 + 0.5f), ch = (int)(s.upper1 + 0.5f);
     if (s.gate0 == 2 && bx.mnx < 0) fast = false;
     if (s.gate0 != 0 && bx.mxx >= cw - 1) fast = false;
     if (s.gate1 == 2 && bx.mny < 0) fast = false;
     if (s.gate1 != 0 && bx.mxy >= ch - 1) fast = false;
+    if (eu5_box_fits<order>(bx) != 1) fast = false;
   }
-  if (!fast || eu5_box_fits<order>(bx) != 1) return false;
+  if (bx.mnx == INT_MAX || !fast) {
+    if (have_n) eu5_load16(p, ct_n, ty_n, x0_n, lane, Tn);
+    return bx.mnx == INT_MAX;                                // nothing inside the frame: done; else: not this way
+  }
   bx.mnx = __builtin_amdgcn_readfirstlane(bx.mnx); bx.mny = __builtin_amdgcn_readfirstlane(bx.mny);
   bx.mxx = __builtin_amdgcn_readfirstlane(bx.mxx); bx.mxy = __builtin_amdgcn_readfirstlane(bx.mxy);
   const unsigned lds_tile = (unsigned)(unsigned long long)(eu4_lds_void)wtile;
+  EU5_STAMP(3);
   eu5_stage<NCH, DEG>(s, bx, lds_tile, lane);
   // the y weights of both pairs, behind the DMA issue
   eu_f2 wyA[order], wyB[order];
@@ -587,7 +657,9 @@ __device__ __forceinline__ bool eu5_tile16h(const eu_render_params &p, const eu4
   const int ibw = bx.mxx - bx.mnx + order;
   const int oAa = hAa ? ((iyAa - bx.mny) * ibw + (ixa - bx.mnx)) * 4 : 0, oAb = hAb ? ((iyAb - bx.mny) * ibw + (ixb - bx.mnx)) * 4 : 0;
   const int oBa = hBa ? ((iyBa - bx.mny) * ibw + (ixa - bx.mnx)) * 4 : 0, oBb = hBb ? ((iyBb - bx.mny) * ibw + (ixb - bx.mnx)) * 4 : 0;
+  EU5_STAMP(4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  EU5_STAMP(5);
   __builtin_amdgcn_sched_barrier(0);
   eu_f2 rga, bxa, rgb, bxb;
   eu5_taps<NCH, DEG>((eu_lptr)wtile, oAa, oAb, ibw * 4, wx, wyA, tx, tyA, rga, bxa, rgb, bxb);
@@ -601,15 +673,27 @@ __device__ __forceinline__ bool eu5_tile16h(const eu_render_params &p, const eu4
     if (hAb) eu_put<NCH>(orow, xb, qb);
   }
   // one pair after the other: interleaved, the two sets of windows do not fit the registers
+  EU5_STAMP(6);
   __builtin_amdgcn_sched_barrier(0);
   eu5_taps<NCH, DEG>((eu_lptr)wtile, oBa, oBb, ibw * 4, wx, wyB, tx, tyB, rga, bxa, rgb, bxb);
   asm volatile("" : "+v"(rga), "+v"(bxa), "+v"(rgb), "+v"(bxb));
+  if (have_n) eu5_load16(p, ct_n, ty_n, x0_n, lane, Tn);
+  __builtin_amdgcn_sched_barrier(0);
   {
     float qa[4] = { rga.x, rga.y, bxa.x, bxa.y }, qb[4] = { rgb.x, rgb.y, bxb.x, bxb.y };
     float *const orow = p.out + (long long)(ycB - p.row_begin) * p.out_stride;
     if (hBa) eu_put<NCH>(orow, xa, qa);
     if (hBb) eu_put<NCH>(orow, xb, qb);
   }
+  EU5_STAMP(7);
+#ifdef EU5_STAMPS
+  if (lane == 0 && w.stamps) {
+    unsigned long long *o = w.stamps + ((size_t)tile_y * w.tiles16 + x0 / EU4_TW) * 8;
+    st_[1] = 6ull | 16ull;      // class: hoist 1, "npass 5" = a 16x16 tile (taps column: pair A only, store column: pair B + stores)
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = st_[k];
+  }
+#endif
   return true;
 }
 
@@ -636,13 +720,29 @@ struct eu5_iter {
   }
   __device__ __forceinline__ bool done() const { return ul * 8 + xcd >= units; }
   __device__ __forceinline__ int row() const { return (ul * 8 + xcd) * UNIT + ry; }
+  // The tile column of the current position: the list's column rotated by an amount that depends on the row.
+  // With K waves per XCD and K a multiple of half the tiles per row (640 = 2.5 x 256 for the headline) wave k
+  // would otherwise render the SAME two tile columns of every row - and the columns through a pole cost two to
+  // four passes per tile, the columns at the face's edge one: the launch then ends with the waves that own
+  // the pole columns (measured: the tiles' own cycles add up to 0.79 ms of a 1.12 ms launch).
+  __device__ __forceinline__ int col() const
+  {
+    const unsigned h = ((unsigned)row() * 0x9E3779B1u) >> 16;
+    int c = rx + (int)((h * (unsigned)tiles16) >> 16);
+    if (c >= tiles16) c -= tiles16;
+    return c;
+  }
 };
 
 // tile rows 2m and 2m + 1 form a 16x16 row of the first loop when both have the same column plan
+// (the plan table is read through the scalar cache: as a vector load its wait - vmcnt counts in issue order -
+// is also a wait for the stores of the tile just finished, 1-2k cycles per iteration)
+typedef const __attribute__((address_space(4))) int *eu5_cint;
 __device__ __forceinline__ int eu5_pair_plan(const int *tileplan, int tiles_y, int m)
 {
   if (2 * m + 1 >= tiles_y) return -1;
-  const int a = tileplan[2 * m], b = tileplan[2 * m + 1];
+  const eu5_cint tp = (eu5_cint)tileplan;
+  const int a = tp[2 * m], b = tp[2 * m + 1];
   return a == b ? a : -1;
 }
 
@@ -663,12 +763,20 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+#ifdef EU5_STAMPS
+  const unsigned long long ws0 = __builtin_amdgcn_s_memtime();
+  unsigned long long ws1 = ws0;
+#endif
   // blocks are dealt round-robin to the 8 XCDs: blockIdx.x & 7 names the XCD (up to a rotation;
   // for speed only)
   const int xcd = (int)(blockIdx.x & 7);
   const int K = (int)(gridDim.x >> 3) * EU5_WAVES;
   const int t0 = (int)(blockIdx.x >> 3) * EU5_WAVES + wave;
   constexpr bool PAIRS = FAST && PRJ == EU_SPHERICAL;
+  // In both loops the plan of the NEXT position is requested before the current tile is rendered: a scalar
+  // load from global memory takes 500+ cycles under this load, and a wave has nothing else to do while it
+  // waits for the plan of the tile it is about to start (measured: 1.6-2.3k cycles per iteration outside
+  // the tiles, a quarter of a wave's life).
   if constexpr (PAIRS) {
     // first the pairs of tile rows with a common column plan, as 16x16 tiles
     eu5_iter<EU5_UNIT_ROWS / 2> it;
@@ -676,47 +784,96 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
     const int rows2 = (p.tiles_y + 1) / 2;
     it.units = (rows2 + EU5_UNIT_ROWS / 2 - 1) / (EU5_UNIT_ROWS / 2);
     it.start(t0, K);
+    // moves `it` on to the next position with a pair plan; false when the list is exhausted
+    auto seek = [&](int &m, int &tcol, int &plan) -> bool {
+      while (!it.done()) {
+        m = it.row();
+        if (m < rows2) {
+          plan = eu5_pair_plan(w.tileplan, p.tiles_y, m);
+          if (plan >= 0) { tcol = it.col(); it.step(); return true; }
+        }
+        it.step();
+      }
+      return false;
+    };
+    int m_c = 0, col_c = 0, plan_c = -1, m_n = 0, col_n = 0, plan_n = -1;
+    bool have_c = seek(m_c, col_c, plan_c);
+    eu5_tab16 Tc, Tn;
+    if (have_c) eu5_load16(p, w.coltab + (size_t)plan_c * p.width * EU4_COL_FLOATS, 2 * m_c, col_c * EU4_TW, lane0, Tc);
 #pragma unroll 1
-    for (; !it.done(); it.step()) {
-      const int m = it.row();
-      if (m >= rows2) continue;
-      const int plan = eu5_pair_plan(w.tileplan, p.tiles_y, m);
-      if (plan < 0) continue;
+    while (have_c) {
+      const bool have_n = seek(m_n, col_n, plan_n);
       int lane = lane0;
       asm volatile("" : "+v"(lane));
-      const float *ct = w.coltab + (size_t)plan * p.width * EU4_COL_FLOATS;
-      if (!eu5_tile16h<NCH, DEG>(p, w, atab, tile, ct, 2 * m, it.rx * EU4_TW, lane)) {
+      const float *ct_n = w.coltab + (size_t)(have_n ? plan_n : 0) * p.width * EU4_COL_FLOATS;
+      if (!eu5_tile16h<NCH, DEG>(p, w, atab, tile, Tc, 2 * m_c, col_c * EU4_TW, lane, have_n, ct_n, 2 * m_n, col_n * EU4_TW, Tn)) {
         // both 16x8 tiles to the direct-gather kernel (a rare event: the +-180 degree seam, a box beyond the slice)
         if (lane < 2) {
-          const int id = (2 * m + lane) * w.tiles16 + it.rx;
+          const int id = (2 * m_c + lane) * w.tiles16 + col_c;
           const int sh = eu4_shard_of(id);
           const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
           p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
         }
       }
+      Tc = Tn; m_c = m_n; col_c = col_n; plan_c = plan_n; have_c = have_n;
     }
   }
+#ifdef EU5_STAMPS
+  ws1 = __builtin_amdgcn_s_memtime();
+#endif
   // XCD x owns the units x, x + 8, ... of EU5_UNIT_ROWS tile rows; its waves walk that list in raster
   // order, wave k taking tiles k, k + K, ...
   eu5_iter<EU5_UNIT_ROWS> it;
   it.xcd = xcd; it.tiles16 = w.tiles16;
   it.units = (p.tiles_y + EU5_UNIT_ROWS - 1) / EU5_UNIT_ROWS;
   it.start(t0, K);
+  if constexpr (PAIRS) {
+    // the rows the first loop left: 16x8 tiles without a column plan (a row whose partner has another plan
+    // does without its own here), each requesting the next one's table values ahead of its stores
+    auto seek = [&](int &ty, int &tcol) -> bool {
+      while (!it.done()) {
+        ty = it.row();
+        if (ty < p.tiles_y && eu5_pair_plan(w.tileplan, p.tiles_y, ty >> 1) < 0) { tcol = it.col(); it.step(); return true; }
+        it.step();
+      }
+      return false;
+    };
+    int ty_c = 0, col_c = 0, ty_n = 0, col_n = 0;
+    bool have_c = seek(ty_c, col_c);
+    eu5_tab8 Tc, Tn;
+    if (have_c) eu5_load8<FAST>(p, ty_c, col_c * EU4_TW, lane0, Tc);
 #pragma unroll 1
-  for (; !it.done(); it.step()) {
-    const int tile_y = it.row();
-    if (tile_y >= p.tiles_y) continue;
-    if (PAIRS && eu5_pair_plan(w.tileplan, p.tiles_y, tile_y >> 1) >= 0) continue;   // rendered by the first loop
-    // everything a tile derives from the lane index is recomputed per tile (kept live across the
-    // loop it costs registers the tile code needs)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int plan = PRJ == EU_SPHERICAL ? w.tileplan[tile_y] : -1;
-    if (plan >= 0)
-      eu5_tile<NCH, DEG, PRJ, PRJ == EU_SPHERICAL, FAST>(p, w, atab, tile, w.coltab + (size_t)plan * p.width * EU4_COL_FLOATS,
-                                                          tile_y, it.rx * EU4_TW, lane);
-    else
-      eu5_tile<NCH, DEG, PRJ, false, FAST>(p, w, atab, tile, nullptr, tile_y, it.rx * EU4_TW, lane);
+    while (have_c) {
+      const bool have_n = seek(ty_n, col_n);
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_c, col_c * EU4_TW, lane, &Tc, have_n, ty_n, col_n * EU4_TW, &Tn);
+      Tc = Tn; ty_c = ty_n; col_c = col_n; have_c = have_n;
+    }
+  } else {
+    int plan_n = (it.done() || it.row() >= p.tiles_y) ? -2 : (PRJ == EU_SPHERICAL ? ((eu5_cint)w.tileplan)[it.row()] : -1);
+#pragma unroll 1
+    while (!it.done()) {
+      const int tile_y = it.row(), tcol = it.col(), plan = plan_n;
+      it.step();
+      plan_n = (it.done() || it.row() >= p.tiles_y) ? -2 : (PRJ == EU_SPHERICAL ? ((eu5_cint)w.tileplan)[it.row()] : -1);
+      if (plan == -2) continue;
+      // everything a tile derives from the lane index is recomputed per tile (kept live across the
+      // loop it costs registers the tile code needs)
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      if (plan >= 0)
+        eu5_tile<NCH, DEG, PRJ, PRJ == EU_SPHERICAL, FAST>(p, w, atab, tile, w.coltab + (size_t)plan * p.width * EU4_COL_FLOATS,
+                                                            tile_y, tcol * EU4_TW, lane);
+      else
+        eu5_tile<NCH, DEG, PRJ, false, FAST>(p, w, atab, tile, nullptr, tile_y, tcol * EU4_TW, lane);
+    }
   }
+#ifdef EU5_STAMPS
+  if (lane0 == 0 && w.stamps) {
+    unsigned long long *o = w.stamps + (size_t)w.tiles16 * p.tiles_y * 8 + ((size_t)blockIdx.x * EU5_WAVES + wave) * 4;
+    o[0] = ws0; o[1] = ws1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = 1;
+  }
+#endif
 }
 
