@@ -359,6 +359,10 @@ def main():
         kernel_name = "eu_render_multi_kernel"
     elif sprj in (5, 6) and degree in (2, 3) and nch in (3, 4) and not twine and os.environ.get("EU_HIP_R4", "") != "0":
         kernel_name = "eu_render4s_kernel (per-wave LDS staging of the footprint) + eu_render4d_kernel (its work list)"
+    elif (sprj == 0 and tprj in (ea.CUBEMAP, ea.RECTILINEAR) and degree in (2, 3) and nch in (3, 4) and not twine
+          and ypr == (0, 0, 0) and world == 1 and os.environ.get("EU_HIP_R4", "") != "0"):
+        kernel_name = ("eu_render5_kernel (persistent waves, per-wave LDS staging of the footprint, 16x16 tiles on rows with a "
+                       "column plan) + eu_render4d_kernel (its work list: the tiles around the poles)")
     elif sprj in (0, 5, 6) and degree in (1, 2, 3):
         kernel_name = ("eu_render2_kernel (packed two-pixel; big cubic lat/lon jobs: + eu_render3_kernel on the row "
                        "runs where source rows run across, launch-level layout choice)")

@@ -23,7 +23,7 @@ extern "C" int eu_launch_render2(const eu_render_params *p, void *stream);
 extern "C" int eu_launch_diag_coords(const eu_src_dev *s, const float *rays_dev, long n, int variant,
                                      float *out_dev, void *stream);
 extern "C" int eu_launch_render4(const eu_render_params *p, const float *h_row, size_t h_row_floats,
-                                 unsigned long long plan_gen, void *stream);
+                                 unsigned long long plan_gen, int only_if_worth, void *stream);
 extern "C" size_t eu_render4_worklist_ints(size_t ntiles);
 extern "C" size_t eu_render4_worklist_header_ints(void);
 extern "C" int eu_launch_to_screen(const float *in, long long in_stride, unsigned *out,
@@ -659,7 +659,11 @@ int launch_render(const eu_render_params *p, void *st)
   // jobs. EU_HIP_R4: 0 never, 1 wherever it applies (tests, A/B runs); read on every call.
   const char *r4env = getenv("EU_HIP_R4");
   const int r4mode = r4env ? atoi(r4env) : -1;
-  const bool use_r4 = r4mode == 1 || (r4mode != 0 && is_cube(p->src.prj) && p->src.degree >= 2);
+  // round 3: also cubic / quadratic lat/lon jobs whose target has column plans (the headline: an upright cubemap),
+  // with the persistent form of the staged kernel (eu_render5_kernel) - eu_launch_render4 declines the others
+  const bool fast5 = p->src.prj == EU_SPHERICAL && p->src.degree >= 2 && p->form == EU_FORM_BA && p->norm_mode == EU_NORM_NONE &&
+                     p->band_count <= 1 && p->src.brighten == 1.0f && p->src.always_hit && !p->twine;
+  const bool use_r4 = r4mode == 1 || (r4mode != 0 && p->src.degree >= 2 && (is_cube(p->src.prj) || fast5));
   // a --mask_for job paints the facet at the inner evaluation: only the general kernels do that
   if (p->src.mask_paint) {
     eu_render_params q = *p;
@@ -682,7 +686,7 @@ int launch_render(const eu_render_params *p, void *st)
     eu_render_params q = *p;
     q.wl = g.wl;
     g.launches += 2;
-    const int rc = eu_launch_render4(&q, g.h_row.data(), g.h_row.size(), g.plan_gen, st);
+    const int rc = eu_launch_render4(&q, g.h_row.data(), g.h_row.size(), g.plan_gen, r4mode != 1, st);
     if (rc <= 0) return rc;
     g.launches -= 2;
   }

@@ -217,15 +217,20 @@ EU_D2 void eu_atan_tab_entry(int idx, float *e)
 
 EU_D2 eu_f2 eu_atanf_pos2_tab(eu_f2 t, const float *tab)
 {
+  // round 3: the table fields feed scalar operations (as operands of packed operations they first had
+  // to be moved into register pairs: 12 v_mov), num = a * t + b is ONE fma (a in {0, 1, 2}: a * t is exact),
+  // and the |t| < 7/16 row (hi = lo = 0) needs no select: 0 - ((xs - 0) - x) is x - xs bit for bit
   const eu_u2 it = eu_bits2(t);
   eu_i2 idx = (eu_i2)(it >> 18) - 0xfb7;
   idx = __builtin_elementwise_min(__builtin_elementwise_max(idx, (eu_i2){ 0, 0 }), (eu_i2){ 80, 80 });
   const float *e0 = tab + idx.x * 8, *e1 = tab + idx.y * 8;
-  const eu_f2 a = { e0[0], e1[0] }, b = { e0[1], e1[1] }, c = { e0[2], e1[2] }, d = { e0[3], e1[3] };
-  const eu_f2 hi = { e0[4], e1[4] }, lo = { e0[5], e1[5] };
-  const eu_i2 small = idx == 0, big = it >= 0x4c000000u;
-  eu_f2 num = a * t + b;
-  eu_f2 den = c * t + d;
+  const float a0 = e0[0], b0 = e0[1], c0 = e0[2], h0 = e0[4], l0 = e0[5];
+  const float a1 = e1[0], b1 = e1[1], c1 = e1[2], h1 = e1[4], l1 = e1[5];
+  const eu_i2 big = it >= 0x4c000000u;
+  const eu_f2 num = { __builtin_fmaf(a0, t.x, b0), __builtin_fmaf(a1, t.y, b1) };
+  float d0 = c0 * t.x, d1 = c1 * t.y;
+  d0 = d0 + a0; d1 = d1 + a1;                 // d == a in every row of the table
+  const eu_f2 den = { d0, d1 };
   eu_f2 x = eu_div2_safe(num, den);
   const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
               aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
@@ -236,9 +241,9 @@ EU_D2 eu_f2 eu_atanf_pos2_tab(eu_f2 t, const float *tab)
   eu_f2 s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
   eu_f2 s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
   eu_f2 xs = x * (s1 + s2);
-  eu_f2 rsmall = x - xs;
-  eu_f2 rmid = hi - ((xs - lo) - x);
-  eu_f2 r = eu_sel2(small, rsmall, rmid);
+  eu_f2 u = { xs.x - l0, xs.y - l1 };
+  u = u - x;
+  const eu_f2 r = { h0 - u.x, h1 - u.y };
   const float hb = 1.5707962513e+00f + 7.5497894159e-08f;
   return eu_sel2(big, (eu_f2){ hb, hb }, r);
 }

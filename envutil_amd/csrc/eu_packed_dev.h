@@ -184,6 +184,21 @@ __device__ __forceinline__ eu_ray2 eu_rays2(int form, int norm_mode, eu_cptr row
   return r;
 }
 
+// x / c for an extent c: eu_div2_rr where its operands are in range (x zero or in [2^-40, 2^40], c in
+// [2^-20, 2^20]: then the same bits as `/`), `/` for the other lanes
+__device__ __forceinline__ eu_f2 eu_div2_ext(eu_f2 x, float c)
+{
+  const eu_u2 ix = eu_bits2(x) & 0x7fffffffu;
+  const eu_i2 okx = (ix == 0u) | ((ix - 0x2b800000u) <= (0x53800000u - 0x2b800000u));
+  const bool okc = c >= 0x1p-20f && c <= 0x1p20f;
+  eu_f2 q = eu_div2_rr(x, c, eu_rcp_refined(c));
+  if (__builtin_expect(!(okc && okx.x && okx.y), 0)) {
+    if (!(okc && okx.x)) q.x = x.x / c;
+    if (!(okc && okx.y)) q.y = x.y / c;
+  }
+  return q;
+}
+
 // ---------------------------------------------------------------------------
 // both lanes: ray -> source pixel coordinate (+ hit mask)
 // ---------------------------------------------------------------------------
@@ -238,8 +253,10 @@ __device__ __forceinline__ eu_i2 eu_coord2(const eu_src_dev &s, const eu_ray2 &r
       i0 = eu_div2_const(i0, s.ext_w, s.rcp_ext_w);
       i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
     } else {
-      i0 = i0 / s.ext_w;
-      i1 = i1 / s.ext_h;
+      // the constant division is not exact for this extent (2 pi and pi are such: every full-sphere
+      // source): the FMA division with the reciprocal formed once, hipcc's `/` for a lane out of range
+      i0 = eu_div2_ext(i0, s.ext_w);
+      i1 = eu_div2_ext(i1, s.ext_h);
     }
     i0 = i0 * s.total_w; i0 = i0 - .5f;
     i1 = i1 * s.total_h; i1 = i1 - .5f;
@@ -383,8 +400,14 @@ __device__ __forceinline__ eu_i2 eu_coord2_ok(const eu_src_dev &s, const eu_ray2
       i0 = eu_div2_const(i0, s.ext_w, s.rcp_ext_w);
       i1 = eu_div2_const(i1, s.ext_h, s.rcp_ext_h);
     } else {
-      i0 = i0 / s.ext_w;
-      i1 = i1 / s.ext_h;
+      // (as eu_div2_ext, with the range test reported in `ok` instead of a fallback)
+      const eu_u2 j0 = eu_bits2(i0) & 0x7fffffffu, j1 = eu_bits2(i1) & 0x7fffffffu;
+      const eu_i2 in0 = (j0 == 0u) | ((j0 - 0x2b800000u) <= (0x53800000u - 0x2b800000u));
+      const eu_i2 in1 = (j1 == 0u) | ((j1 - 0x2b800000u) <= (0x53800000u - 0x2b800000u));
+      const int okc = (s.ext_w >= 0x1p-20f && s.ext_w <= 0x1p20f && s.ext_h >= 0x1p-20f && s.ext_h <= 0x1p20f) ? -1 : 0;
+      ok = ok & in0 & in1 & (eu_i2){ okc, okc };
+      i0 = eu_div2_rr(i0, s.ext_w, eu_rcp_refined(s.ext_w));
+      i1 = eu_div2_rr(i1, s.ext_h, eu_rcp_refined(s.ext_h));
     }
     i0 = i0 * s.total_w; i0 = i0 - .5f;
     i1 = i1 * s.total_h; i1 = i1 - .5f;

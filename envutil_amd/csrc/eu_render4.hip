@@ -586,8 +586,11 @@ template <int NCH, int DEG, int PRJ>
 static int launch4_ndp(const eu_render_params &p, const eu4_plan &w, hipStream_t st)
 {
   // EU_HIP_R5: 1 (default) the persistent staged kernel of round 3, 0 round 2's one-tile-per-workgroup form
+  // (unset: the persistent kernel for lat/lon sources - headline 1.13 vs 1.22 ms for the launch-level hybrid of
+  // the direct-gather kernels -, round 2's form for cubemap sources: config 3 1.00 vs 1.22 ms)
   const char *r5env = getenv("EU_HIP_R5");
-  if (!(r5env && r5env[0] == '0')) {
+  const bool use5 = r5env ? r5env[0] != '0' : PRJ == EU_SPHERICAL;
+  if (use5) {
     // as many workgroups as are resident at once (a persistent kernel must not queue a second round)
     static const int per_cu_env = [] { const char *e = getenv("EU_HIP_R5_WGS"); return e ? atoi(e) : 0; }();   // A/B runs
     static const int cus = [] {
@@ -671,6 +674,7 @@ struct plan_cache {
   int *tileplan = nullptr; size_t tileplan_cap = 0;
   float *coltab = nullptr; size_t coltab_cap = 0;
   float *atab = nullptr;
+  int planned_rows = 0;      // tile rows with a column plan
 } g4;
 
 bool ensure_atab()
@@ -693,8 +697,11 @@ void launch_colplan(const eu_render_params &p, float *ct, const float *k, hipStr
 // h_row: the host copy of the plan's row table (whole frame), plan_gen: changes whenever the
 // stepper tables change. Returns 1 when the job is outside this kernel's coverage (the caller
 // goes on to eu_launch_render2 / eu_launch_render).
+// only_if_worth: take a lat/lon job only where the staged kernels measured faster than the direct-gather ones
+// (cubic / quadratic, the FAST profile, column plans on at least half of the tile rows: an upright cubemap or
+// rectilinear target); 0: every job they cover (EU_HIP_R4=1: tests, A/B runs)
 extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row, size_t h_row_floats,
-                                 unsigned long long plan_gen, void *stream)
+                                 unsigned long long plan_gen, int only_if_worth, void *stream)
 {
   eu_render_params p = *pp;
   if (p.twine || p.stage != 0 || p.form >= EU_FORM_FISH || p.src.has_lcp || p.nch_out != p.nch) return 1;
@@ -768,6 +775,8 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
     // the previous launch may still read the old plans
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     if (hipMemcpy(g4.tileplan, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    g4.planned_rows = 0;
+    for (int v : tp) g4.planned_rows += v >= 0;
     for (size_t j = 0; j < plans.size() / 4; j++) {
       float *ct = g4.coltab + j * (size_t)p.width * EU4_COL_FLOATS;
       switch (p.src.degree) {
@@ -778,6 +787,9 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
       if (hipGetLastError() != hipSuccess) return -1;
     }
     g4.key.swap(key);
+  }
+  if (only_if_worth && p.src.prj == EU_SPHERICAL) {
+    if (p.src.degree < 2 || g4.planned_rows * 2 < p.tiles_y) return 1;
   }
   w.tileplan = g4.tileplan;
   w.coltab = g4.coltab;

@@ -796,26 +796,40 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
       }
       return false;
     };
-    int m_c = 0, col_c = 0, plan_c = -1, m_n = 0, col_n = 0, plan_n = -1;
-    bool have_c = seek(m_c, col_c, plan_c);
-    eu5_tab16 Tc, Tn;
-    if (have_c) eu5_load16(p, w.coltab + (size_t)plan_c * p.width * EU4_COL_FLOATS, 2 * m_c, col_c * EU4_TW, lane0, Tc);
-#pragma unroll 1
-    while (have_c) {
-      const bool have_n = seek(m_n, col_n, plan_n);
-      int lane = lane0;
-      asm volatile("" : "+v"(lane));
-      const float *ct_n = w.coltab + (size_t)(have_n ? plan_n : 0) * p.width * EU4_COL_FLOATS;
-      if (!eu5_tile16h<NCH, DEG>(p, w, atab, tile, Tc, 2 * m_c, col_c * EU4_TW, lane, have_n, ct_n, 2 * m_n, col_n * EU4_TW, Tn)) {
-        // both 16x8 tiles to the direct-gather kernel (a rare event: the +-180 degree seam, a box beyond the slice)
-        if (lane < 2) {
-          const int id = (2 * m_c + lane) * w.tiles16 + col_c;
-          const int sh = eu4_shard_of(id);
-          const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
-          p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
-        }
+    // two copies of the body, the table values alternating between Ta and Tb: handing them from "next" to
+    // "current" by assignment is a use, and a use is a wait for the loads that have just been requested
+    int m_a = 0, col_a = 0, plan_a = -1, m_b = 0, col_b = 0, plan_b = -1;
+    bool have_a = seek(m_a, col_a, plan_a), have_b = false;
+    eu5_tab16 Ta, Tb;
+    if (have_a) eu5_load16(p, w.coltab + (size_t)plan_a * p.width * EU4_COL_FLOATS, 2 * m_a, col_a * EU4_TW, lane0, Ta);
+    auto fallback = [&](int m, int tcol, int lane) {
+      // both 16x8 tiles to the direct-gather kernel (a rare event: the +-180 degree seam, a box beyond the slice)
+      if (lane < 2) {
+        const int id = (2 * m + lane) * w.tiles16 + tcol;
+        const int sh = eu4_shard_of(id);
+        const int slot = atomicAdd(p.wl + EU4_WL_SHARD(sh), 1);
+        p.wl[EU4_WL_ENTRIES + (size_t)slot * EU4_SHARDS + sh] = id;
       }
-      Tc = Tn; m_c = m_n; col_c = col_n; plan_c = plan_n; have_c = have_n;
+    };
+#pragma unroll 1
+    while (have_a) {
+      {
+        have_b = seek(m_b, col_b, plan_b);
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const float *ct_n = w.coltab + (size_t)(have_b ? plan_b : 0) * p.width * EU4_COL_FLOATS;
+        if (!eu5_tile16h<NCH, DEG>(p, w, atab, tile, Ta, 2 * m_a, col_a * EU4_TW, lane, have_b, ct_n, 2 * m_b, col_b * EU4_TW, Tb))
+          fallback(m_a, col_a, lane);
+      }
+      if (!have_b) break;
+      {
+        have_a = seek(m_a, col_a, plan_a);
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const float *ct_n = w.coltab + (size_t)(have_a ? plan_a : 0) * p.width * EU4_COL_FLOATS;
+        if (!eu5_tile16h<NCH, DEG>(p, w, atab, tile, Tb, 2 * m_b, col_b * EU4_TW, lane, have_a, ct_n, 2 * m_a, col_a * EU4_TW, Ta))
+          fallback(m_b, col_b, lane);
+      }
     }
   }
 #ifdef EU5_STAMPS
@@ -838,17 +852,25 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
       }
       return false;
     };
-    int ty_c = 0, col_c = 0, ty_n = 0, col_n = 0;
-    bool have_c = seek(ty_c, col_c);
-    eu5_tab8 Tc, Tn;
-    if (have_c) eu5_load8<FAST>(p, ty_c, col_c * EU4_TW, lane0, Tc);
+    int ty_a = 0, col_a = 0, ty_b = 0, col_b = 0;
+    bool have_a = seek(ty_a, col_a), have_b = false;
+    eu5_tab8 Ta, Tb;
+    if (have_a) eu5_load8<FAST>(p, ty_a, col_a * EU4_TW, lane0, Ta);
 #pragma unroll 1
-    while (have_c) {
-      const bool have_n = seek(ty_n, col_n);
-      int lane = lane0;
-      asm volatile("" : "+v"(lane));
-      eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_c, col_c * EU4_TW, lane, &Tc, have_n, ty_n, col_n * EU4_TW, &Tn);
-      Tc = Tn; ty_c = ty_n; col_c = col_n; have_c = have_n;
+    while (have_a) {
+      {
+        have_b = seek(ty_b, col_b);
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_a, col_a * EU4_TW, lane, &Ta, have_b, ty_b, col_b * EU4_TW, &Tb);
+      }
+      if (!have_b) break;
+      {
+        have_a = seek(ty_a, col_a);
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_b, col_b * EU4_TW, lane, &Tb, have_a, ty_a, col_a * EU4_TW, &Ta);
+      }
     }
   } else {
     int plan_n = (it.done() || it.row() >= p.tiles_y) ? -2 : (PRJ == EU_SPHERICAL ? ((eu5_cint)w.tileplan)[it.row()] : -1);
