@@ -1650,6 +1650,20 @@ static int mount_coordinate(const mount_t *m, const float *ray, float *crd3)
   return 1;
 }
 
+/* --mask_for: what the facet's evaluator yields instead of the interpolated pixel px (nch floats, in place).
+ * masking_t (1 or 3 channels: the paint, unconditionally) or alpha_masking_t (2 or 4: colour = paint * alpha,
+ * alpha kept), masking.h:70-135. mask_paint 1: painted black, 2: painted white. Pinned against the reference's
+ * own functors through oracle/ref_zimt.cc (ref_masking / ref_alpha_masking). */
+void euo_mask_paint(int nch, int mask_paint, float *px)
+{
+  const float paint = mask_paint == 2 ? 1.0f : 0.0f;
+  if (nch == 1 || nch == 3) for (int c = 0; c < nch; c++) px[c] = paint;
+  else {
+    px[0] = paint * px[nch - 1];
+    if (nch == 4) px[1] = px[2] = px[0];
+  }
+}
+
 /* returns the hit mask; px gets nch floats */
 static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
 {
@@ -1661,17 +1675,7 @@ static int mount_eval(const mount_t *m, const float *ray, float *px, float *dbg)
     return 0;
   }
   ev_eval(&m->ev, crd3[0], crd3[1], px);
-  if (m->src->mask_paint) {
-    /* the facet's evaluator is masking_t (1 or 3 channels: the paint, unconditionally) or
-     * alpha_masking_t (2 or 4: colour = paint * alpha, alpha kept), masking.h:70-135 */
-    const int n = m->src->spl.nch;
-    const float paint = m->src->mask_paint == 2 ? 1.0f : 0.0f;
-    if (n == 1 || n == 3) for (int c = 0; c < n; c++) px[c] = paint;
-    else {
-      px[0] = paint * px[n - 1];
-      if (n == 4) px[1] = px[2] = px[0];
-    }
-  }
+  if (m->src->mask_paint) euo_mask_paint(m->src->spl.nch, m->src->mask_paint, px);
   return 1;
 }
 

@@ -175,6 +175,7 @@ void   euo_facet_alpha(float *alpha, int w, int h, int npolys, const int *counts
                        const float *ys, int crop_kind, int cx0, int cx1, int cy0, int cy1, int stage);
 /* the binomial alone, in place (pinned against zimt::convolve through oracle/_ref) */
 void   euo_binomial_plane(float *plane, int w, int h);
+void   euo_mask_paint(int nch, int mask_paint, float *px);   /* masking_t / alpha_masking_t, masking.h:70-135 */
 void   euo_source_coordinates(const euo_source *src, const float *rays, long n, float *out3);
 void   euo_prj_to_ray_d(int projection, const double *in2, double *out3);
 void   euo_ray_to_prj_d(int projection, const double *in3, double *out2);

@@ -17,6 +17,9 @@
 //     arguments of environment.h:833-843)
 //   * the PTO lens polynomial lcp            (lens_correction.h: it includes nothing
 //     but zimt/eval.h, so it compiles in place)
+//   * masking_t / alpha_masking_t            (masking.h: zimt/bspline.h + zimt/eval.h only), round 3
+//   * pto_parser_type                        (pto.h: standard library only, behind <iostream> as in
+//     envutil_main.cc), round 3
 // envutil's other headers (geometry.h, stepper.h, environment.h, cubemap.h,
 // twining.h) cannot be compiled here: every one of them reaches
 // envutil_basic.h:198-200, which includes OpenImageIO (absent from the image).
@@ -32,6 +35,10 @@
 #include "zimt/eval.h"
 #include "zimt/convolve.h"
 #include "lens_correction.h"
+#include "masking.h"        // masking_t / alpha_masking_t: includes nothing but zimt/bspline.h and zimt/eval.h
+#include <iostream>         // pto.h uses std::cerr / std::cout and leaves the include to envutil_main.cc
+#include "pto.h"            // pto_parser_type: <map>, <vector>, <fstream>, <regex>
+#include <string>
 
 namespace {
 
@@ -308,4 +315,92 @@ extern "C" void ref_binomial_alpha(float *plane, long w, long h)
   zimt::view_t<2, float> alpha(plane, {1L, w}, {std::size_t(w), std::size_t(h)});
   zimt::convolve(alpha, alpha, {zimt::REFLECT, zimt::REFLECT},
                  {1.0 / 16.0, 4.0 / 16.0, 6.0 / 16.0, 4.0 / 16.0, 1.0 / 16.0}, 2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// round 3: masking.h and pto.h compile in place as well
+// ---------------------------------------------------------------------------------------------------
+
+// masking_t<2, C, L>: the paint, unconditionally (masking.h:74-93); n pixels of C channels
+template <int C> static void masking_run(float paint, long n, float *out)
+{
+  project::masking_t<2, C, L> f(paint);
+  typedef zimt::simdized_type<zimt::xel_t<float, 2>, L> in_v;
+  typedef zimt::simdized_type<zimt::xel_t<float, C>, L> out_v;
+  for (long i0 = 0; i0 < n; i0 += long(L)) {
+    in_v in; out_v o;
+    for (int d = 0; d < 2; d++) for (std::size_t l = 0; l < L; l++) in[d][l] = 0.0f;
+    f.eval(in, o);
+    for (std::size_t l = 0; l < L && i0 + long(l) < n; l++)
+      for (int c = 0; c < C; c++) out[(i0 + l) * C + c] = o[c][l];
+  }
+}
+extern "C" void ref_masking(int nch, float paint, long n, float *out)
+{
+  switch (nch) {
+    case 1: masking_run<1>(paint, n, out); break;
+    case 2: masking_run<2>(paint, n, out); break;
+    case 3: masking_run<3>(paint, n, out); break;
+    case 4: masking_run<4>(paint, n, out); break;
+  }
+}
+
+// alpha_masking_t<C, L> (masking.h:95-135) over the spline of a handle made by ref_bspline_new, evaluated at
+// n spline coordinates (x, y): colour = paint * alpha, alpha kept
+template <int C> static void alpha_masking_run(handle_base *hb, float paint, const float *crd, long n, float *out)
+{
+  auto *h = static_cast<handle<C> *>(hb);
+  typedef typename handle<C>::spl_t spl_t;
+  std::shared_ptr<spl_t> sp(h->sp.get(), [](spl_t *) {});      // the handle keeps owning the spline
+  project::alpha_masking_t<C, L> f(paint, sp);
+  typedef zimt::simdized_type<zimt::xel_t<float, 2>, L> in_v;
+  typedef zimt::simdized_type<zimt::xel_t<float, C>, L> out_v;
+  for (long i0 = 0; i0 < n; i0 += long(L)) {
+    in_v in; out_v o;
+    for (std::size_t l = 0; l < L; l++) {
+      const long i = i0 + long(l) < n ? i0 + long(l) : n - 1;
+      in[0][l] = crd[2 * i]; in[1][l] = crd[2 * i + 1];
+    }
+    f.eval(in, o);
+    for (std::size_t l = 0; l < L && i0 + long(l) < n; l++)
+      for (int c = 0; c < C; c++) out[(i0 + l) * C + c] = o[c][l];
+  }
+}
+extern "C" void ref_alpha_masking(void *h, float paint, const float *crd, long n, float *out)
+{
+  handle_base *hb = (handle_base *)h;
+  if (hb->nch == 2) alpha_masking_run<2>(hb, paint, crd, n, out);
+  else if (hb->nch == 4) alpha_masking_run<4>(hb, paint, crd, n, out);
+}
+
+// pto_parser_type (pto.h:72-180): parse the lines of `text` (one PTO line per '\n') and write the line groups
+// in a canonical form - "head<TAB>index<TAB>field=value<TAB>field=value...\n", groups and fields in the order of
+// the parser's own std::map - into out (at most cap bytes incl. the terminator). Returns the length needed.
+extern "C" long ref_pto_parse(const char *text, char *out, long cap)
+{
+  pto_parser_type parser;
+  std::string all(text), line;
+  std::size_t pos = 0;
+  while (pos <= all.size()) {
+    std::size_t e = all.find('\n', pos);
+    if (e == std::string::npos) e = all.size();
+    line = all.substr(pos, e - pos);
+    parser.parse_pto_line(line);
+    pos = e + 1;
+  }
+  std::string res;
+  for (const auto &g : parser.line_group) {
+    int idx = 0;
+    for (const auto &ln : g.second) {
+      res += g.first + "\t" + std::to_string(idx++);
+      for (const auto &f : ln.field_map) res += "\t" + f.first + "=" + f.second;
+      res += "\n";
+    }
+  }
+  if (out && cap > 0) {
+    const long n = (long)res.size() < cap - 1 ? (long)res.size() : cap - 1;
+    std::memcpy(out, res.data(), (size_t)n);
+    out[n] = 0;
+  }
+  return (long)res.size() + 1;
 }

@@ -157,3 +157,24 @@ def binomial_alpha(plane):
     f.argtypes = [C.c_void_p, C.c_long, C.c_long]
     f(out.ctypes.data, out.shape[1], out.shape[0])
     return out
+
+
+def masking(nch, paint, n):
+    """masking_t<2, nch, 16> (masking.h:74-93) on n pixels"""
+    out = np.full((n, nch), np.nan, np.float32)
+    f = lib().ref_masking
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_float, C.c_long, C.c_void_p]
+    f(nch, paint, n, ptr(out))
+    return out
+
+
+def alpha_masking(spline, paint, crd):
+    """alpha_masking_t<nch, 16> (masking.h:95-135) over a RefSpline of 2 or 4 channels at spline coordinates crd"""
+    crd = np.ascontiguousarray(crd, np.float32)
+    out = np.zeros((crd.shape[0], spline.nch), np.float32)
+    f = lib().ref_alpha_masking
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_long, C.c_void_p]
+    f(spline.h_, paint, ptr(crd), crd.shape[0], ptr(out))
+    return out
