@@ -13,7 +13,7 @@ from .api import (  # noqa: F401
     EuError, Facet, Source, Target, arguments, facet_spec, get_dispatch,
     container_geometry, cubemap_metrics, device_count, get_extent, get_step,
     lib, lib_path, make_spread, render, render_timed, build, band_rows, band_frame_rows,
-    layout_segments, facet_alpha,
+    layout_segments, facet_alpha, init_devices, device_slots, device_strips, render_devices,
     SPHERICAL, CYLINDRICAL, RECTILINEAR, STEREOGRAPHIC, FISHEYE, CUBEMAP, BIATAN6,
     BC_MIRROR, BC_PERIODIC, BC_REFLECT, BC_NATURAL, BC_CONSTANT,
 )

@@ -128,6 +128,9 @@ def lib():
     L.eu_hip_source_update_facet.argtypes = [vp, vp]
     L.eu_hip_source_release.argtypes = [vp]
     L.eu_hip_render.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
+    L.eu_hip_init_devices.argtypes = [vp, i32]
+    L.eu_hip_render_devices.argtypes = [vp, vp, i32, vp, C.c_size_t, i32]
+    L.eu_hip_device_strips.argtypes = [vp, vp, i32, vp, vp]
     L.eu_hip_render_timed.argtypes = [vp, vp, i32, vp, C.c_size_t, i32, vp]
     L.eu_hip_layout_segments.argtypes = [vp, vp, i32, vp, i32, vp]
     L.eu_hip_band_rows.argtypes = [i32, i32, i32, i32]
@@ -465,6 +468,49 @@ def render(args, sources, nchannels=None, row_begin=0, row_end=None, stage=0, ou
     arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
     _check(lib().eu_hip_render(C.byref(t), arr, len(sources), out.ctypes.data_as(C.c_void_p),
                                w * och * 4, 0, None))
+    return out
+
+
+def init_devices(devices):
+    """one process, several devices: one slot per entry (the same device may be listed twice)"""
+    arr = (C.c_int * len(devices))(*devices)
+    _check(lib().eu_hip_init_devices(arr, len(devices)))
+
+
+def device_slots():
+    return lib().eu_hip_device_slots()
+
+
+def device_strips(args, sources, nchannels=None):
+    """the rows eu_hip_render_devices gives every slot for this job: [(begin, end), ...]"""
+    if not isinstance(sources, (list, tuple)):
+        sources = [sources]
+    nch = nchannels or sources[0].fct.nchannels
+    t = args.target(nch, 0, None, 0, None)
+    n = device_slots()
+    b, e = (C.c_int * n)(), (C.c_int * n)()
+    arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
+    _check(lib().eu_hip_device_strips(C.byref(t), arr, len(sources), b, e))
+    return list(zip(list(b), list(e)))
+
+
+def render_devices(args, sources, nchannels=None, out=None, out_dev_ptr=None):
+    """the whole frame, its rows tiled over the device slots (eu_hip_render_devices): into host memory
+    (returned) or, with out_dev_ptr, into device memory of slot 0"""
+    if not isinstance(sources, (list, tuple)):
+        sources = [sources]
+    nch = nchannels or sources[0].fct.nchannels
+    t = args.target(nch, 0, None, 0, None)
+    rows = t.row_end - t.row_begin
+    w = args.out_width
+    och = 1 if args.tethered else nch
+    arr = (C.c_void_p * len(sources))(*[s.handle for s in sources])
+    if out_dev_ptr is not None:
+        _check(lib().eu_hip_render_devices(C.byref(t), arr, len(sources), C.c_void_p(out_dev_ptr), w * och * 4, 1))
+        return None
+    if out is None:
+        out = np.zeros((rows, w), np.uint32) if args.tethered else np.zeros((rows, w, och), np.float32)
+    _check(lib().eu_hip_render_devices(C.byref(t), arr, len(sources), out.ctypes.data_as(C.c_void_p), w * och * 4, 0))
     return out
 
 

@@ -50,6 +50,11 @@ struct eu_source {
   float *dev;            // braced container in HBM
   size_t nfloats;
   eu_src_dev sd;
+  // several devices in one process (eu_hip_init_devices): the device slot this container lives on and its
+  // copies on the other slots (made on first use by eu_hip_render_devices, freed with the source)
+  int slot = 0;
+  eu_source *replica[EU_MAX_SLOTS] = {};
+  bool is_replica = false;
 };
 
 namespace {
@@ -91,7 +96,14 @@ struct context {
   eu_src_dev *msrc = nullptr; size_t msrc_cap = 0;
   std::vector<unsigned char> mplan_key;
   int mplan_form = 0, mplan_norm = 0;
-} g;
+  float *strip = nullptr; size_t strip_cap = 0;   // eu_hip_render_devices: this slot's rows before they are gathered
+};
+// One context per device SLOT. A process that never calls eu_hip_init_devices has one slot (one process per
+// GPU, the set-up bench.py's multi-rank runs use); eu_hip_init_devices makes a slot per listed device, and every
+// entry point works on the current one (`g`).
+context ctx_[EU_MAX_SLOTS];
+int nslots_ = 1, cur_slot_ = 0;
+#define g (ctx_[cur_slot_])
 
 #define HIPCHK(call)                                                          \
   do {                                                                        \
@@ -99,6 +111,13 @@ struct context {
     if (e_ != hipSuccess)                                                     \
       return fail(EU_ERR_NO_DEVICE, std::string(#call ": ") + hipGetErrorString(e_)); \
   } while (0)
+
+int set_slot(int k)
+{
+  cur_slot_ = k;
+  if (ctx_[k].device >= 0) HIPCHK(hipSetDevice(ctx_[k].device));
+  return EU_OK;
+}
 
 // per-device state: the library's stream and to_screen_t's sRGB LUT. Used by the implicit
 // initialisation and by eu_hip_init; switching devices while sources or tables of the old
@@ -990,6 +1009,11 @@ int eu_hip_source_info(const eu_source *src, eu_container *geom, int *nch)
 int eu_hip_source_release(eu_source *src)
 {
   if (!src) return EU_OK;
+  for (int k = 0; k < EU_MAX_SLOTS; k++)
+    if (src->replica[k]) {
+      if (src->replica[k]->dev) (void)hipFree(src->replica[k]->dev);
+      delete src->replica[k];
+    }
   if (src->dev) (void)hipFree(src->dev);
   delete src;
   return EU_OK;
@@ -1085,6 +1109,178 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   HIPCHK(hipStreamSynchronize(g.copy));
   HIPCHK(hipStreamSynchronize(st));
   return EU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one process, several devices (include/eu_hip.h)
+// ---------------------------------------------------------------------------------------------------------
+int eu_hip_device_slots(void) { return nslots_; }
+int eu_current_slot(void) { return cur_slot_; }
+
+int eu_hip_init_devices(const int *devices, int ndevices)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(EU_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (!devices || ndevices < 1 || ndevices > EU_MAX_SLOTS) return fail(EU_ERR_ARGUMENT, "1 .. EU_MAX_SLOTS devices");
+  for (int k = 0; k < ndevices; k++)
+    if (devices[k] < 0 || devices[k] >= n) return fail(EU_ERR_ARGUMENT, "device index out of range");
+  // slot 0 may already be initialised (sources exist on it): it keeps its device
+  if (ctx_[0].device >= 0 && ctx_[0].device != devices[0])
+    return fail(EU_ERR_ARGUMENT, "the library is already initialised on another device than devices[0]");
+  for (int k = 1; k < nslots_; k++)
+    if (k >= ndevices || ctx_[k].device != devices[k])
+      return fail(EU_ERR_ARGUMENT, "device slots cannot be re-assigned once made");
+  int rc = EU_OK;
+  for (int k = 0; k < ndevices && !rc; k++) {
+    cur_slot_ = k;
+    if (ctx_[k].device < 0) rc = init_device(devices[k]);
+    // peers: slot k reads slot 0's containers and slot 0 receives the strips (a no-op for the same device)
+    if (!rc && devices[k] != devices[0]) {
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, devices[k], devices[0]);
+      if (can) { hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0); if (e != hipSuccess) (void)hipGetLastError(); }
+    }
+  }
+  nslots_ = std::max(nslots_, ndevices);
+  int rc2 = set_slot(0);
+  return rc ? rc : rc2;
+}
+
+namespace {
+
+// the source's copy on slot k (made on first use: one peer copy of the braced container)
+int replica_of(eu_source *src, int k, eu_source **out)
+{
+  if (k == src->slot) { *out = src; return EU_OK; }
+  if (!src->replica[k]) {
+    eu_source *r = new (std::nothrow) eu_source(*src);
+    if (!r) return fail(EU_ERR_NO_DEVICE, "out of host memory");
+    for (int j = 0; j < EU_MAX_SLOTS; j++) r->replica[j] = nullptr;
+    r->is_replica = true; r->slot = k; r->dev = nullptr;
+    int rc = set_slot(k);
+    if (rc) { delete r; return rc; }
+    hipError_t e = hipMalloc((void **)&r->dev, src->nfloats * sizeof(float));
+    if (e == hipSuccess) {
+      if (ctx_[k].device == ctx_[src->slot].device)
+        e = hipMemcpyAsync(r->dev, src->dev, src->nfloats * sizeof(float), hipMemcpyDeviceToDevice, g.stream);
+      else
+        e = hipMemcpyPeerAsync(r->dev, ctx_[k].device, src->dev, ctx_[src->slot].device, src->nfloats * sizeof(float), g.stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) { if (r->dev) (void)hipFree(r->dev); delete r; return fail(EU_ERR_NO_DEVICE, hipGetErrorString(e)); }
+    // the evaluator parameters are the original's (same geometry, same verified constants) on another base
+    r->sd.base = r->dev + (src->sd.base - src->dev);
+    src->replica[k] = r;
+  } else if (memcmp(&src->replica[k]->fct, &src->fct, sizeof(eu_facet))) {
+    // the facet's geometry changed since (eu_hip_source_update_facet): same container, new mount
+    eu_source *r = src->replica[k];
+    const float *base = r->sd.base;
+    r->fct = src->fct; r->sd = src->sd; r->sd.base = base;
+  }
+  *out = src->replica[k];
+  return EU_OK;
+}
+
+// contiguous strips of equal estimated cost: the segments the layout probe marks (source rows running across
+// target rows: the polar faces of a cubemap made from a lat/lon image) cost ~1.6x the others with every kernel
+void cost_strips(const eu_target *trg, eu_source *const *srcs, int nsrc, int n, int *begin, int *end)
+{
+  const int H = frame_h(trg);
+  std::vector<unsigned char> flags((size_t)(H / EU_SEG_ROWS + 2), 0);
+  int seg = EU_SEG_ROWS, nseg = 0;
+  if (nsrc == 1) {
+    nseg = eu_hip_layout_segments(trg, srcs, 1, flags.data(), (int)flags.size(), &seg);
+    if (nseg < 0) nseg = 0;
+  }
+  auto cost_upto = [&](int y) {          // cost of rows [0, y)
+    double c = 0.0;
+    for (int k = 0; k * seg < y; k++) {
+      const int a = k * seg, b = std::min(y, a + seg);
+      c += (b - a) * ((k < nseg && flags[(size_t)k]) ? 1.6 : 1.0);
+    }
+    return c;
+  };
+  const double total = cost_upto(H);
+  int prev = 0;
+  for (int k = 0; k < n; k++) {
+    int y = H;
+    if (k + 1 < n) {
+      const double want = total * (k + 1) / n;
+      int lo = prev, hi = H;
+      while (lo < hi) { const int mid = (lo + hi) / 2; if (cost_upto(mid) < want) lo = mid + 1; else hi = mid; }
+      y = std::min(H, (lo + 15) / 16 * 16);          // whole 16-row tile rows (the staged kernel's pairs)
+    }
+    begin[k] = prev; end[k] = std::max(prev, y);
+    prev = end[k];
+  }
+}
+
+}  // namespace
+
+int eu_hip_device_strips(const eu_target *trg, eu_source *const *srcs, int nsrc, int *begin, int *end)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if (!trg || !srcs || nsrc < 1 || !begin || !end) return fail(EU_ERR_ARGUMENT, "null argument");
+  if ((rc = check_target(trg))) return rc;
+  cost_strips(trg, srcs, nsrc, nslots_, begin, end);
+  return EU_OK;
+}
+
+int eu_hip_render_devices(const eu_target *trg, eu_source *const *srcs, int nsrc, float *out,
+                          size_t out_row_stride_bytes, int out_on_device)
+{
+  int rc;
+  if ((rc = ensure_init())) return rc;
+  if (nslots_ <= 1) return eu_hip_render(trg, srcs, nsrc, out, out_row_stride_bytes, out_on_device, nullptr);
+  if (!trg || !srcs || nsrc < 1 || !out) return fail(EU_ERR_ARGUMENT, "no source / no output");
+  if ((rc = check_target(trg))) return rc;
+  if (trg->band_count > 1 || trg->row_begin != 0 || trg->row_end != frame_h(trg))
+    return fail(EU_ERR_ARGUMENT, "eu_hip_render_devices renders whole frames (it does the tiling itself)");
+  if (nsrc > 64) return fail(EU_ERR_UNSUPPORTED, "more than 64 facets over several devices");
+  const int och = trg->out_format == EU_OUT_SRGBA8 ? 1 : trg->stage ? 3 : trg->nchannels;
+  const size_t min_stride = (size_t)frame_w(trg) * och * sizeof(float);
+  if (out_row_stride_bytes < min_stride || out_row_stride_bytes % sizeof(float))
+    return fail(EU_ERR_ARGUMENT, "row stride smaller than a row / not a multiple of 4 bytes");
+  int begin[EU_MAX_SLOTS], end[EU_MAX_SLOTS];
+  cost_strips(trg, srcs, nsrc, nslots_, begin, end);
+  // every slot: its replicas, its strip into its own buffer, the strip's way to `out` behind it on the
+  // slot's stream; the slots run concurrently, one host thread feeds them
+  struct guard { ~guard() { for (int k = 0; k < nslots_; k++) { cur_slot_ = k; if (ctx_[k].device >= 0 && hipSetDevice(ctx_[k].device) == hipSuccess && ctx_[k].stream) (void)hipStreamSynchronize(ctx_[k].stream); } cur_slot_ = 0; if (ctx_[0].device >= 0) (void)hipSetDevice(ctx_[0].device); } } sync_all_on_exit;
+  for (int k = 0; k < nslots_; k++) {
+    if (end[k] <= begin[k]) continue;
+    eu_source *reps[64];
+    for (int f = 0; f < nsrc; f++) {
+      if (!srcs[f]) return fail(EU_ERR_HANDLE, "null source");
+      if ((rc = replica_of(srcs[f], k, &reps[f]))) return rc;
+    }
+    if ((rc = set_slot(k))) return rc;
+    eu_target t = *trg;
+    t.row_begin = begin[k]; t.row_end = end[k];
+    const size_t rows = (size_t)(end[k] - begin[k]);
+    const bool direct = out_on_device && ctx_[k].device == ctx_[0].device && out_row_stride_bytes == min_stride;
+    float *dst = nullptr;
+    if (direct) dst = out + (size_t)begin[k] * (min_stride / sizeof(float));
+    else {
+      if ((rc = grow(&g.strip, &g.strip_cap, rows * (min_stride / sizeof(float))))) return rc;
+      dst = g.strip;
+    }
+    if ((rc = render_on_device(&t, reps, nsrc, dst, min_stride, g.stream))) return rc;
+    if (!direct) {
+      char *o = (char *)out + (size_t)begin[k] * out_row_stride_bytes;
+      if (!out_on_device)
+        HIPCHK(hipMemcpy2DAsync(o, out_row_stride_bytes, dst, min_stride, min_stride, rows, hipMemcpyDeviceToHost, g.stream));
+      else if (ctx_[k].device == ctx_[0].device)
+        HIPCHK(hipMemcpy2DAsync(o, out_row_stride_bytes, dst, min_stride, min_stride, rows, hipMemcpyDeviceToDevice, g.stream));
+      else if (out_row_stride_bytes == min_stride)
+        HIPCHK(hipMemcpyPeerAsync(o, ctx_[0].device, dst, ctx_[k].device, rows * min_stride, g.stream));
+      else
+        for (size_t r = 0; r < rows; r++)
+          HIPCHK(hipMemcpyPeerAsync(o + r * out_row_stride_bytes, ctx_[0].device, (char *)dst + r * min_stride, ctx_[k].device, min_stride, g.stream));
+    }
+  }
+  return EU_OK;      // the guard waits for every slot
 }
 
 // the layout choice per segment of the (cropped) frame for this job: flags[k] = 1 where

@@ -668,6 +668,7 @@ extern "C" size_t eu_render4_worklist_header_ints(void) { return EU4_WL_ENTRIES;
 // rx, rz and everything derived from them alone are functions of the column). Tile rows
 // with the same four constants share a table.
 // ---------------------------------------------------------------------------
+extern "C" int eu_current_slot(void);
 namespace {
 struct plan_cache {
   std::vector<unsigned char> key;
@@ -675,7 +676,9 @@ struct plan_cache {
   float *coltab = nullptr; size_t coltab_cap = 0;
   float *atab = nullptr;
   int planned_rows = 0;      // tile rows with a column plan
-} g4;
+} g4s[EU_MAX_SLOTS];
+// one cache per device slot (eu_api.hip: eu_hip_init_devices)
+#define g4 (g4s[eu_current_slot()])
 
 bool ensure_atab()
 {

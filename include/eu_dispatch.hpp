@@ -23,6 +23,8 @@
 #include <fstream>
 #include <map>
 #include <string>
+#include <cstdlib>
+#include <algorithm>
 #include <vector>
 #include "eu_hip.h"
 
@@ -44,8 +46,8 @@ struct facet_base : public extent_type
   double shear_g = 0.0, shear_t = 0.0;
   double s = 0.0, a = 0.0, b = 0.0, c = 0.0, d = 0.0, h = 0.0, v = 0.0;
   bool has_shift = false, has_lcp = false, has_shear = false;
-  // PTO translation and reprojection plane (envutil_basic.h:441-446): parsed by the front
-  // end, rendered by code outside this path (generic_r3 / tf_ex_facet): payload() refuses them
+  // PTO translation and reprojection plane (envutil_basic.h:441-446): parsed by the front end and handed
+  // to the library (eu_facet.tr_*, tp_*), which renders such facets with the generic stepper
   double tr_x = 0.0, tr_y = 0.0, tr_z = 0.0, tp_y = 0.0, tp_p = 0.0, tp_r = 0.0;
 
   // facet_base::process_geometry, envutil_basic.h:499-521
@@ -272,11 +274,31 @@ struct hip_dispatch : public dispatch_base
       single_fct = to_eu(args.facet_spec_v[size_t(args.single)]);
       t.single = &single_fct;
     }
+    // a node with several GPUs: the output rows tiled over all of them behind the same call (one device slot
+    // per GPU, the sources replicated by peer copies on first use; eu_hip.h: eu_hip_render_devices).
+    // EU_HIP_DEVICES=n limits the slots, =1 keeps the single-device path.
+    static const int slots = [] {
+      int n = eu_hip_device_count();
+      if (const char *e = std::getenv("EU_HIP_DEVICES")) n = std::min(n, std::max(1, std::atoi(e)));
+      n = std::min(n, int(EU_MAX_SLOTS));
+      if (n > 1) {
+        std::vector<int> dev(size_t(n), 0);
+        for (int k = 0; k < n; k++) dev[size_t(k)] = k;
+        if (eu_hip_init_devices(dev.data(), n) != 0) n = 1;
+      }
+      return n;
+    }();
     if (args.tethered) {
       t.out_format = EU_OUT_SRGBA8;
+      if (slots > 1)
+        return eu_hip_render_devices(&t, srcs.data(), int(srcs.size()), (float *)args.p_screen_data,
+                                     size_t(w) * sizeof(uint32_t), 0);
       return eu_hip_render(&t, srcs.data(), int(srcs.size()), (float *)args.p_screen_data,
                            size_t(w) * sizeof(uint32_t), 0, nullptr);
     }
+    if (slots > 1)
+      return eu_hip_render_devices(&t, srcs.data(), int(srcs.size()), args.p_output,
+                                   size_t(w) * nchannels * sizeof(float), 0);
     return eu_hip_render(&t, srcs.data(), int(srcs.size()), args.p_output,
                          size_t(w) * nchannels * sizeof(float), 0, nullptr);
   }

@@ -168,6 +168,22 @@ int  eu_hip_device_count(void);
 int  eu_hip_init(int device);                 /* selects the device for this process */
 const char *eu_hip_last_error(void);
 
+/* ---- one process, several devices (round 3; SURVEY 8e: the output rows tiled across the GPUs of a node;
+ * the reference has no counterpart - its payload() runs on the host's cores) --------------------------------
+ * eu_hip_init_devices makes one device SLOT per entry of `devices` (at most EU_MAX_SLOTS; the same device may
+ * be listed more than once: separate streams, tables and buffers - how a one-GPU box tests this). Sources are
+ * created on slot 0 as before; eu_hip_render_devices replicates them onto the other slots on first use
+ * (hipMemcpyPeerAsync over xGMI: the "broadcast of the source environment"), cuts the frame into contiguous
+ * strips of equal estimated cost, renders strip k on slot k - all slots concurrently - and gathers the strips
+ * into `out` (a host buffer, or device memory of slot 0: peer copies). Same pixels as eu_hip_render. */
+#define EU_MAX_SLOTS 16
+int  eu_hip_init_devices(const int *devices, int ndevices);
+int  eu_hip_device_slots(void);               /* 1 unless eu_hip_init_devices was called */
+int  eu_hip_render_devices(const eu_target *trg, eu_source *const *srcs, int nsrc, float *out,
+                           size_t out_row_stride_bytes, int out_on_device);
+/* the rows [begin[k], end[k]) eu_hip_render_devices gives slot k for this job (nslots entries each) */
+int  eu_hip_device_strips(const eu_target *trg, eu_source *const *srcs, int nsrc, int *begin, int *end);
+
 /* ---- set-up arithmetic shared with the reference's host code ------------- */
 /* get_extent / get_vfov / get_step, envutil_basic.cc:49-229 */
 int  eu_hip_get_extent(int projection, int width, int height, double hfov,
