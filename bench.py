@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (source (prj, w, h, hfov), target (prj, w, h, hfov), nch, degree, twine, ypr)
     "headline": (("spherical", 16384, 8192, 360.0), ("cubemap", 4096, 24576, 90.0), 3, 3, 0, (0, 0, 0)),
+    # BASELINE config 1 (the reference's own CPU-runnable case: plumbing; 1 Mpix - a test case, not a bench line)
+    "config1": (("spherical", 2048, 1024, 360.0), ("rectilinear", 1024, 1024, 90.0), 3, 1, 0, (0, 0, 0)),
     "config2": (("spherical", 8192, 4096, 360.0), ("cubemap", 2048, 12288, 90.0), 3, 1, 0, (0, 0, 0)),
     "config3": (("cubemap", 2048, 12288, 90.0), ("spherical", 16384, 8192, 360.0), 3, 3, 0, (0, 0, 0)),
     "config4": (("spherical", 32768, 16384, 360.0), ("spherical", 32768, 16384, 360.0), 3, 1, 3, (30, 15, 7.5)),
@@ -46,6 +48,7 @@ WORKLOADS = {
 }
 WORKLOAD_TEXT = {
     "headline": "16384x8192 lat/lon -> 6x4096 cubemap, b-spline degree 3 + prefilter, RGB f32",
+    "config1": "2048x1024 lat/lon -> 1024x1024 rectilinear, hfov 90, bilinear, RGB f32",
     "config2": "8192x4096 lat/lon -> 6x2048 cubemap, bilinear, RGB f32",
     "config3": "6x2048 cubemap -> 16384x8192 spherical, b-spline degree 3 + prefilter, RGB f32",
     "config4": "32768x16384 lat/lon -> 32768x16384 spherical, ypr 30/15/7.5, 3x3 twining, bilinear, RGB f32",
@@ -339,11 +342,12 @@ def main():
     # per rank: the WHOLE source (a rank's rows of a cubemap or spherical target span all
     # longitudes, band-interleaved shares all latitudes too) + its own output rows
     alg_bytes = 4.0 * nch * (n_src + npix_rank)
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # (a rank without rows - more ranks than row units - has launched nothing: no rate to report)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
 
     # HBM traffic is a RECORD, not measured in this run: PMC counters need rocprofv3 passes of
     # their own (tools/gpu_prof.sh); profiles/traffic.json holds the last ones, with their round
-    traffic, traffic_source = None, None
+    traffic, traffic_source, profile_ms, profile_frac = None, None, None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf) and world == 1:
         try:
@@ -351,7 +355,11 @@ def main():
             w_ = rec.get("workloads", {}).get(a.workload)
             if w_:
                 traffic = w_.get("hbm_bytes_per_step")
-                traffic_source = f"profiles/traffic.json, {rec.get('round')}: {w_.get('kernels')}"
+                traffic_source = f"profiles/traffic.json, {rec.get('round')} at commit {rec.get('commit')}: {w_.get('kernels')}"
+                # the fraction the committed rocprofv3 summary certifies (profiled runs clock lower): beside the live one
+                profile_ms = w_.get("kernel_ms_profile")
+                if profile_ms:
+                    profile_frac = round(alg_bytes / (profile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         except Exception:
             traffic = None
 
@@ -394,9 +402,13 @@ def main():
                                      "render_to_host_ms": None if host_ms is None else round(host_ms, 1),
                                      "d2h_reference": pcie,
                                      "note": "render_to_host = kernel + D2H of the frame into the caller's pageable buffer; not part of value"}},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                     "bytes_counted": "this rank: the whole source + its own output rows" if world > 1 else "the job's algorithmic bytes",
+                     "frac_of_job_bytes_over_n": None if (achieved is None or world == 1) else round(
+                         4.0 * nch * (n_src + npix_total) / world / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_ms_profile": profile_ms, "frac_profile": profile_frac,
                      "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                      "kernel_ms_note": "HIP events on the launch stream around the timed steps, per step",
                      "kernel_ms_pre": round(kernel_ms_pre, 4),

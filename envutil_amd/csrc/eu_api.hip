@@ -1093,6 +1093,8 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
   for (size_t c = 0; c < 4; c++)
     if (!g.chunk_done[c]) HIPCHK(hipEventCreateWithFlags(&g.chunk_done[c], hipEventDisableTiming));
   const size_t per = ((rows + nchunk - 1) / nchunk + 7) / 8 * 8;
+  // whatever happens below, nothing of this call may still write into `out` or read g.stage when it returns
+  struct drain { hipStream_t a, b; ~drain() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); } } drain_on_exit{ g.copy, st };
   for (size_t c = 0; c < nchunk; c++) {
     const size_t a = std::min(rows, c * per), b = std::min(rows, (c + 1) * per);
     if (a >= b) break;

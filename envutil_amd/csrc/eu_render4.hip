@@ -629,7 +629,12 @@ static int launch4_ndp(const eu_render_params &p, const eu4_plan &w, hipStream_t
   }
   if (hipGetLastError() != hipSuccess) return -1;
   hipLaunchKernelGGL((eu_render4d_kernel<NCH, DEG, PRJ>), dim3(EU4_DIRECT_WGS), dim3(256), 0, st, p, w);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (hipGetLastError() != hipSuccess) {
+    // the staged kernel has filled the lists and nobody will empty them: the next job must not append to them
+    (void)hipMemsetAsync(p.wl, 0, EU4_WL_ENTRIES * sizeof(int), st);
+    return -1;
+  }
+  return 0;
 }
 
 template <int NCH, int DEG>
@@ -676,6 +681,7 @@ struct plan_cache {
   float *coltab = nullptr; size_t coltab_cap = 0;
   float *atab = nullptr;
   int planned_rows = 0;      // tile rows with a column plan
+  hipStream_t last_stream = nullptr;   // where the plans were last read
 } g4s[EU_MAX_SLOTS];
 // one cache per device slot (eu_api.hip: eu_hip_init_devices)
 #define g4 (g4s[eu_current_slot()])
@@ -734,7 +740,8 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
     const int v[8] = { p.width, p.row_begin, p.row_end, p.band_shift, p.band_count, p.band_index, p.form, p.norm_mode };
     memcpy(q, v, sizeof v);
   }
-  if (key != g4.key) {
+  // (cubemap / biatan6 sources never read the tile plan: no plans, no upload, no synchronisation for them)
+  if (p.src.prj == EU_SPHERICAL && key != g4.key) {
     std::vector<int> tp((size_t)p.tiles_y, -1);
     std::vector<float> plans;          // 4 floats per plan: A0, A2, B0, B2
     const bool can = p.src.prj == EU_SPHERICAL && p.form == EU_FORM_BA && p.norm_mode == EU_NORM_NONE && h_row;
@@ -775,8 +782,10 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
       if (hipMalloc((void **)&g4.coltab, need * sizeof(float)) != hipSuccess) return -1;
       g4.coltab_cap = need;
     }
-    // the previous launch may still read the old plans
+    // the previous launch may still read the old plans - on this stream or on the one the plans were last
+    // used on (the library's own stream and a caller's stream alternate)
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (g4.last_stream && g4.last_stream != st && hipStreamSynchronize(g4.last_stream) != hipSuccess) return -1;
     if (hipMemcpy(g4.tileplan, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
     g4.planned_rows = 0;
     for (int v : tp) g4.planned_rows += v >= 0;
@@ -796,6 +805,7 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
   }
   w.tileplan = g4.tileplan;
   w.coltab = g4.coltab;
+  g4.last_stream = st;
 #ifdef EU5_STAMPS
   // diagnostic build: stamps of every tile, averaged per pass count / plan kind after the launch
   static unsigned long long *d_st = nullptr; static size_t st_cap = 0; static int dumps = 0;

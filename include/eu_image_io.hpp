@@ -162,6 +162,11 @@ inline bool read_header(FILE *f, header &h, std::string &err)
     err = "unsupported image geometry";
     return false;
   }
+  // integer formats carry their MAXVAL (1 .. 65535); without one the samples would be read as raw floats
+  if (magic[0] == 'P' && magic[1] >= '5' && magic[1] <= '7' && magic.size() == 2 && h.maxval < 1) {
+    err = "PNM / PAM header without a MAXVAL between 1 and 65535";
+    return false;
+  }
   h.data_offset = std::ftell(f);
   return true;
 }

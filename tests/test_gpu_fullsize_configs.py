@@ -1,4 +1,4 @@
-"""Parity at BASELINE.json's full sizes for configs 2 - 5 (the headline is in
+"""Parity at BASELINE.json's full sizes for configs 1 - 5 (the headline is in
 test_gpu_fullsize.py): the sources are built on the GPU as bench.py builds them, the oracle
 renders bands of rows of the real frame from the coefficients the GPU built (downloaded), and
 the GPU's rows must be the same bits. Config 4 (9 coordinate chains per pixel on a 6.4 GB
@@ -71,6 +71,12 @@ def check_rows(name, starts, rows=8):
         os.environ.pop("EU_HIP_R4", None)
         for g in gs:
             g.release()
+
+
+def test_config1_whole_frame_bit_identical():
+    """2048x1024 lat/lon -> 1024x1024 rectilinear, hfov 90, bilinear (BASELINE config 1, the reference's own
+    CPU-runnable case): 1 Mpix - the WHOLE frame against the oracle, under every kernel selection"""
+    check_rows("config1", (0,), rows=1024)
 
 
 def test_config2_rows_bit_identical():

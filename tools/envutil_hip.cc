@@ -1,7 +1,7 @@
 // envutil_hip - envutil's command line on the MI355X path.
 //
 //   envutil_hip --facet pano.pfm spherical 360 0 0 0 --projection cubemap --hfov 90
-//               --width 1024 --spline_degree 3 --output cube.pfm
+//               --width 1024 --degree 3 --output cube.pfm
 //   envutil_hip --pto project.pto --output pano.pfm
 //   envutil_hip <fixed options> -          (pipe mode: one job per line of stdin)
 //
@@ -13,6 +13,7 @@
 // reference's asset_handler keeps them in RAM. There is no CPU rendering path: without an
 // MI355X every job fails with the library's error.
 #include <cstdio>
+#include <cstring>
 #include <iostream>
 #include <map>
 #include <string>
@@ -47,8 +48,19 @@ static std::vector<std::string> tokenize(const std::string &s)
 }
 
 // image_series (envutil_basic.h:207-262): a format string with one %-sequence taking an integer
+// The reference formats whenever the string holds exactly one '%' and returns it verbatim otherwise; a
+// conversion other than an integer one ("%s", "%n") is undefined behaviour there. Here the one '%' has to
+// introduce "%[flags][width]d" (or i / u / x / X / o) - anything else is returned verbatim, never handed to printf
+// (the string arrives from the command line and, in pipe mode, from stdin).
 static std::string series_name(const std::string &fmt, int index)
 {
+  size_t npct = 0, pos = 0;
+  for (size_t i = 0; i < fmt.size(); i++) if (fmt[i] == '%') { npct++; pos = i; }
+  if (npct != 1) return fmt;
+  size_t k = pos + 1;
+  while (k < fmt.size() && (fmt[k] == '0' || fmt[k] == '-' || fmt[k] == '+' || fmt[k] == ' ')) k++;
+  while (k < fmt.size() && fmt[k] >= '0' && fmt[k] <= '9') k++;
+  if (k >= fmt.size() || !std::strchr("diuxXo", fmt[k]) || k - pos > 8) return fmt;
   std::vector<char> buf(fmt.size() + 32);
   std::snprintf(buf.data(), buf.size(), fmt.c_str(), index);
   return buf.data();
