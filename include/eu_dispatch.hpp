@@ -78,6 +78,8 @@ struct facet_spec : public facet_base
   int facet_no = 0;
   int nchannels = 3;
   std::string filename, projection_str;
+  std::string colour_space;       // what the file's samples are in: the PTO i-line's Csp clause, else --input_colour_space,
+                                  // else (empty) what the file itself says (envutil_main.cc:640-670, envutil_basic.h:950-977)
   std::string asset_key;          // residency key (environment.h:84-227)
   float brighten = 1.0f;
   int masked = -1;                // --mask_for (envutil_main.cc:1080-1092)
@@ -100,6 +102,8 @@ struct arguments : public facet_base
   bool twine_normalize = false, twine_precise = false;
   float brighten = 1.0f;
   std::string output, split, synopsis = "panorama", pto_file, twf_file, projection_str;
+  // envutil_main.cc:400-437: the working space and the output's default to "Linear", the input's to "" (the file's own)
+  std::string input_colour_space, working_colour_space = "Linear", colour_space = "Linear";
   int solo = -1, single = -1, mask_for = -1;
   std::vector<std::array<float, 3>> twine_spread;
   int support_min = 8, tile_size = 64;

@@ -9,7 +9,8 @@
 // eu_dispatch.hpp. What the reference gets from OpenImageIO here is an image file's width,
 // height and channel count (facet_base::get_image_metrics, envutil_basic.h:546-589): the host
 // passes a callback for that (`image_probe`). Everything that is file I/O or colour
-// management stays out: colour-space options (accepted, stored nowhere), the
+// management stays out: the colour-space options are parsed and stored (arguments::*_colour_space,
+// facet_spec::colour_space) for the program that owns the files (tools/envutil_hip.cc converts), the
 // --oiio pass-through options. --photo images take projection and hfov from the metadata the probe reports.
 //
 // Errors: the reference asserts or exits; this returns false and a message.
@@ -181,6 +182,9 @@ inline bool init_arguments(int argc, const char *const *argv, const image_probe 
   a.twf_file = str("--twf_file", "");
   a.split = str("--split", "");
   a.synopsis = str("--synopsis", "panorama");
+  a.input_colour_space = str("--input_colour_space", "");
+  a.working_colour_space = str("--working_colour_space", "Linear");
+  a.colour_space = str("--output_colour_space", "Linear");
   a.prefilter_degree = in("--prefilter", -1);
   a.spline_degree = in("--degree", 1);
   a.twine = in("--twine", -1);
@@ -291,6 +295,8 @@ inline bool init_arguments(int argc, const char *const *argv, const image_probe 
         } else {
           f.filename = unquote(dir["n"]);
           f.asset_key = f.filename;
+          // envutil's extension of the i-line: Csp"name", else the blanket --input_colour_space (envutil_main.cc:642-670)
+          f.colour_space = dir.count("Csp") && !dir["Csp"].empty() ? unquote(dir["Csp"]) : a.input_colour_space;
           const int prj = std::stoi(dir["f"]);
           if (prj == 0) f.projection = RECTILINEAR;
           else if (prj == 1) f.projection = CYLINDRICAL;
@@ -372,6 +378,7 @@ inline bool init_arguments(int argc, const char *const *argv, const image_probe 
     facet_spec f;
     f.filename = v[0];
     f.projection_str = v[1];
+    f.colour_space = a.input_colour_space;
     // facet_spec::init (envutil_main.cc:104-176): hfov -1 and the projection "metadata" (what --photo
     // passes for both) are read from the image's metadata, with 65 degrees / rectilinear where absent
     // (get_image_metrics, envutil_basic.h:589-625)

@@ -3,10 +3,18 @@
 // The reference reads and writes every format through OpenImageIO (read_image_data /
 // save_array, envutil_basic.h:710-986), which this image does not have. What the path needs
 // from a file is what those two functions hand over: interleaved float pixels, x fastest, the
-// file's own channel count - and nothing else (no colour conversion: the reference only converts
-// when the file's colour space differs from the working one, and none of the formats below
-// carries one). Formats, chosen because they need no library and hold linear float or plain
-// integer samples:
+// file's own channel count - and the colour space the samples are in, because the reference converts
+// every image whose colour space differs from the working one (envutil_basic.h:950-977) and the output
+// when the output's differs (:786-812). OpenImageIO labels a file by its format (oiio:ColorSpace):
+// float formats (PFM, Radiance) are linear, 8/16-bit integer formats are display-referred. Here:
+// file_colour_space() says "Linear" for .pfm / .hdr / .pic and "sRGB" for PNM / PAM, and convert_colour()
+// knows the transfer pairs of OpenImageIO's built-in configuration (no OpenColorIO): sRGB <-> linear (IEC
+// 61966-2-1 piecewise curve), Rec709 <-> linear (BT.709 OETF) - the alpha channel is not touched - and the
+// names "Linear" / "linear" / "scene_linear" / "lin_srgb" / "lin_rec709", "sRGB" / "srgb" / "sRGB - Texture" /
+// "srgb_tx", "Rec709" / "rec709". Any other name is an error message, not silence. DIFFERENCE from the
+// reference, stated in INTEGRATION.md: which label OpenImageIO gives a PNM file (sRGB or Rec709, by version)
+// cannot be checked here; --input_colour_space / the PTO's Csp clause override it as in the reference.
+// Formats, chosen because they need no library and hold linear float or plain integer samples:
 //   .pfm            Portable Float Map: "Pf" 1 channel, "PF" 3 channels, "PF4" 4 channels (the
 //                   extension several tools use for RGBA); float32, either byte order, rows
 //                   bottom to top
@@ -297,6 +305,55 @@ inline bool read_one(const std::string &name, header &h, float *dst, std::string
 }
 
 // a facet's pixels: a single image, or six cube faces stacked to the 1:6 image
+// ---- colour spaces (envutil_basic.h:786-812, :950-977; OpenImageIO's built-in ColorConfig) -----------------
+enum colour_class { CSP_UNKNOWN = 0, CSP_LINEAR = 1, CSP_SRGB = 2, CSP_REC709 = 3 };
+inline colour_class classify_colour_space(const std::string &name)
+{
+  std::string n;
+  for (char c : name) n += char(c >= 'A' && c <= 'Z' ? c - 'A' + 'a' : c);
+  if (n == "linear" || n == "scene_linear" || n == "lin_srgb" || n == "lin_rec709" || n == "linear rec.709 (srgb)") return CSP_LINEAR;
+  if (n == "srgb" || n == "srgb - texture" || n == "srgb_tx" || n == "srgb_texture" || n == "srgb encoded rec.709 (srgb)") return CSP_SRGB;
+  if (n == "rec709" || n == "rec.709") return CSP_REC709;
+  return CSP_UNKNOWN;
+}
+// what the format says about its samples (OpenImageIO: oiio:ColorSpace)
+inline std::string file_colour_space(const std::string &name)
+{
+  const std::string e = lower_ext(name);
+  return (e == "pfm" || e == "hdr" || e == "pic") ? "Linear" : "sRGB";
+}
+inline float to_linear(colour_class c, float v)
+{
+  if (c == CSP_SRGB) return v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
+  if (c == CSP_REC709) return v < 0.081f ? v / 4.5f : std::pow((v + 0.099f) / 1.099f, 1.0f / 0.45f);
+  return v;
+}
+inline float from_linear(colour_class c, float v)
+{
+  if (c == CSP_SRGB) return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+  if (c == CSP_REC709) return v < 0.018f ? 4.5f * v : 1.099f * std::pow(v, 0.45f) - 0.099f;
+  return v;
+}
+// npix pixels of nch interleaved channels from colour space `from` to `to`, in place; the alpha channel (the
+// last of 2 or 4) stays. False with a message for a name this table does not know.
+inline bool convert_colour(float *px, size_t npix, int nch, const std::string &from, const std::string &to, std::string &err)
+{
+  if (from == to) return true;
+  const colour_class a = classify_colour_space(from), b = classify_colour_space(to);
+  if (a == CSP_UNKNOWN || b == CSP_UNKNOWN) {
+    err = "colour space '" + (a == CSP_UNKNOWN ? from : to) + "' is not known here (known: Linear / scene_linear / lin_srgb, sRGB, Rec709; OpenColorIO configurations are not read)";
+    return false;
+  }
+  if (a == b) return true;
+  const int ncol = (nch == 2 || nch == 4) ? nch - 1 : nch;
+  for (size_t i = 0; i < npix; i++)
+    for (int c = 0; c < ncol; c++) {
+      float &v = px[i * size_t(nch) + c];
+      v = from_linear(b, to_linear(a, v));
+    }
+  return true;
+}
+
 inline bool read_image(const std::string &name, std::vector<float> &pixels, int &width, int &height,
                        int &nchannels, std::string &err)
 {

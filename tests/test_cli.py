@@ -103,8 +103,9 @@ def test_latlon_to_cubemap_files(cli, tmp_path):
         face = np.clip(want[64 * i:64 * (i + 1)], 0, 1)
         assert (q == (face * np.float32(65535) + np.float32(0.5)).astype(np.uint32)).all()
     # ... and the six faces read back as a cubemap source
+    # (the faces were written in the working space: told so, they are read without a conversion)
     r = cli(["--facet", "face_%s.pam", "cubemap", "90", "0", "0", "0", "--projection", "spherical", "--hfov", "360",
-             "--width", "128", "--degree", "1", "--twine", "0", "--output", "back.pfm"], tmp_path)
+             "--width", "128", "--degree", "1", "--twine", "0", "--input_colour_space", "Linear", "--output", "back.pfm"], tmp_path)
     assert r.returncode == 0, r.stderr
     faces = np.concatenate([np.frombuffer((tmp_path / f"face_{n}.pam").read_bytes().partition(b"ENDHDR\n")[2], ">u2")
                             .reshape(64, 64, 3) for n in ["left", "right", "top", "bottom", "front", "back"]])
@@ -168,22 +169,55 @@ def test_pipe_mode_keeps_assets_resident(cli, tmp_path):
         assert (bits(read_pfm(tmp_path / name)) == bits(want)).all(), name
 
 
+def srgb_to_linear(v):
+    v = v.astype(np.float32)
+    return np.where(v <= np.float32(0.04045), v / np.float32(12.92),
+                    np.power((v + np.float32(0.055)) / np.float32(1.055), np.float32(2.4))).astype(np.float32)
+
+
+def linear_to_srgb(v):
+    v = v.astype(np.float32)
+    return np.where(v <= np.float32(0.0031308), np.float32(12.92) * v,
+                    np.float32(1.055) * np.power(np.maximum(v, 0), np.float32(1.0 / 2.4)) - np.float32(0.055)).astype(np.float32)
+
+
 @pytest.mark.gpu
 def test_eight_bit_input(cli, tmp_path):
+    """integer formats are display-referred (OpenImageIO labels them; the reference converts every image whose
+    colour space differs from the working one, envutil_basic.h:950-977): a P6 file is read as sRGB and taken to the
+    working space (Linear); the output stays in the working space unless --output_colour_space says otherwise
+    (:786-812). --input_colour_space overrides the file's label. Unknown names are an error, not silence."""
     rng = np.random.default_rng(9)
     q = rng.integers(0, 256, (40, 80, 3), dtype=np.uint8)
     (tmp_path / "in.ppm").write_bytes(b"P6\n# a comment\n80 40\n255\n" + q.tobytes())
-    r = cli(["--facet", "in.ppm", "spherical", "360", "0", "0", "0", "--projection", "spherical", "--hfov", "360",
-             "--width", "80", "--degree", "1", "--twine", "0", "--output", "out.ppm"], tmp_path)
-    assert r.returncode == 0, r.stderr
-    raw = (tmp_path / "out.ppm").read_bytes()
-    # the target's projection and hfov travel as comment lines, as envutil attaches them to its output
-    assert raw.startswith(b"P6\n# Projection: spherical\n# Hfov: 360\n80 40\n255\n")
-    got = np.frombuffer(raw.split(b"80 40\n255\n", 1)[1], np.uint8).reshape(40, 80, 3)
-    img = (q.astype(np.float32) / np.float32(255)).astype(np.float32)
-    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 80, 40, 360.0), img, 1)
-    want = ea.render(ea.arguments(ea.SPHERICAL, 80, 40, 360.0, spline_degree=1), src)
-    assert (got == (np.clip(want, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint32)).all()
+    base = ["--facet", "in.ppm", "spherical", "360", "0", "0", "0", "--projection", "spherical", "--hfov", "360",
+            "--width", "80", "--degree", "1", "--twine", "0"]
+
+    def run(extra, name):
+        r = cli(base + extra + ["--output", name], tmp_path)
+        assert r.returncode == 0, r.stderr
+        raw = (tmp_path / name).read_bytes()
+        # the target's projection and hfov travel as comment lines, as envutil attaches them to its output
+        assert raw.startswith(b"P6\n# Projection: spherical\n# Hfov: 360\n80 40\n255\n")
+        return np.frombuffer(raw.split(b"80 40\n255\n", 1)[1], np.uint8).reshape(40, 80, 3).astype(np.int32)
+
+    def expect(img, back=None):
+        src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 80, 40, 360.0), img, 1)
+        want = ea.render(ea.arguments(ea.SPHERICAL, 80, 40, 360.0, spline_degree=1), src)
+        if back is not None:
+            want = back(want)
+        return (np.clip(want, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.int32)
+
+    raw = (q.astype(np.float32) / np.float32(255)).astype(np.float32)
+    # the file's own label: sRGB -> Linear on the way in (numpy's powf against the C library's: one count of slack)
+    assert np.abs(run([], "out.ppm") - expect(srgb_to_linear(raw))).max() <= 1
+    # told that the samples are linear: no conversion at all - exact
+    assert (run(["--input_colour_space", "Linear"], "lin.ppm") == expect(raw)).all()
+    # and back to sRGB on the way out
+    assert np.abs(run(["--output_colour_space", "sRGB"], "srgb.ppm") - expect(srgb_to_linear(raw), linear_to_srgb)).max() <= 1
+    # a colour space this build does not know is refused with a message
+    r = cli(base + ["--input_colour_space", "ACEScg", "--output", "x.ppm"], tmp_path)
+    assert r.returncode != 0 and "ACEScg" in r.stderr and "not known" in r.stderr
 
 
 @pytest.mark.gpu

@@ -8,8 +8,9 @@
 // The same options, defaults and PTO handling as the reference's main() / core()
 // (envutil_main.cc:1634-1727, :1948-1982): include/eu_frontend.hpp fills project::args,
 // get_dispatch()->payload() renders (include/eu_dispatch.hpp -> libeu_hip.so), and the images
-// go through include/eu_image_io.hpp (PFM / PNM / PAM instead of OpenImageIO; no colour
-// management). Sources stay resident in HBM between the jobs of a pipe-mode session, as the
+// go through include/eu_image_io.hpp (PFM / PNM / PAM / Radiance instead of OpenImageIO; the sRGB / Rec709 /
+// linear transfer pairs of OpenImageIO's built-in colour configuration, --input / --working / --output_colour_space
+// and the PTO's Csp clause honoured, any other colour space an error message). Sources stay resident in HBM between the jobs of a pipe-mode session, as the
 // reference's asset_handler keeps them in RAM. There is no CPU rendering path: without an
 // MI355X every job fails with the library's error.
 #include <cstdio>
@@ -84,6 +85,11 @@ static int run_payload(const std::string &output)
   io::metadata meta;
   meta.projection = projection_name[args.projection];
   meta.hfov = (180.0 / M_PI) * args.hfov;
+  // save_array: from the working colour space to the output's where they differ (envutil_basic.h:786-812)
+  if (!io::convert_colour(out.data(), size_t(ow) * oh, args.nchannels, args.working_colour_space, args.colour_space, err)) {
+    std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
+    return 1;
+  }
   if (!io::write_image(output, out.data(), ow, oh, args.nchannels, cube, err, &meta)) {
     std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
     return 1;
@@ -127,6 +133,17 @@ static int core(int argc, const char *const *argv)
     if (!io::read_image(f.filename, pixels[k], w, h, nch, err)) {
       std::fprintf(stderr, "envutil_hip: %s\n", err.c_str());
       return 2;
+    }
+    // read_image_data: from the facet's colour space - Csp clause / --input_colour_space, else what the file's
+    // format says - to the working one (envutil_basic.h:950-977)
+    {
+      const std::string csp = f.colour_space.empty() ? io::file_colour_space(f.filename) : f.colour_space;
+      if (args.verbose && csp != args.working_colour_space)
+        std::printf("converting %s from %s to %s\n", f.filename.c_str(), csp.c_str(), args.working_colour_space.c_str());
+      if (!io::convert_colour(pixels[k].data(), size_t(w) * h, nch, csp, args.working_colour_space, err)) {
+        std::fprintf(stderr, "envutil_hip: %s: %s\n", f.filename.c_str(), err.c_str());
+        return 2;
+      }
     }
     const bool cube = f.projection == CUBEMAP || f.projection == BIATAN6;
     if (w != f.window_width || (cube ? h != 6 * w : h != f.window_height)) {
