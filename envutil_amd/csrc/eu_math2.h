@@ -332,6 +332,16 @@ EU_D2 eu_f2 eu_sqrt2_ok(eu_f2 x, eu_i2 &ok)
 //   * t >= 2^25 (the reference returns atanhi[3] + atanlo[3]) is reported in `big` instead of
 //     being selected: the caller hands such a tile to the kernel with the fallbacks.
 // ---------------------------------------------------------------------------
+// A float literal formed where it is used (device: s_mov_b32 into a fresh scalar register, volatile so that it
+// is neither hoisted out of the persistent loop nor kept live across it). The eleven coefficients of atanf's
+// polynomial, kept live as loop invariants, are a quarter of the scalar registers eu_render5_kernel has, and
+// what does not fit is spilled into VGPR lanes: 74 v_readlane / v_writelane per 16x16 tile.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EU_LIT(name, value) float name; asm volatile("s_mov_b32 %0, %1" : "=s"(name) : "i"(__builtin_bit_cast(int, (float)(value))))
+#else
+#define EU_LIT(name, value) const float name = (value)
+#endif
+
 // atanf(|q|) for both lanes; big.x / big.y: |q| >= 2^25 (the result of that lane is not valid)
 EU_D2 eu_f2 eu_atanf_abs2_lean(eu_f2 q, const float *tab, eu_i2 &big)
 {
@@ -349,12 +359,12 @@ EU_D2 eu_f2 eu_atanf_abs2_lean(eu_f2 q, const float *tab, eu_i2 &big)
   d0 = d0 + a0; d1 = d1 + a1;                 // d == a in every row of the table
   const eu_f2 den = { d0, d1 };
   const eu_f2 x = eu_div2_safe(num, den);
-  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
-              aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
-              aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
-              aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
   const eu_f2 z = x * x;
   const eu_f2 w = z * z;
+  EU_LIT(aT0, 3.3333334327e-01f); EU_LIT(aT1, -2.0000000298e-01f); EU_LIT(aT2, 1.4285714924e-01f);
+  EU_LIT(aT3, -1.1111110449e-01f); EU_LIT(aT4, 9.0908870101e-02f); EU_LIT(aT5, -7.6918758452e-02f);
+  EU_LIT(aT6, 6.6610731184e-02f); EU_LIT(aT7, -5.8335702866e-02f); EU_LIT(aT8, 4.9768779427e-02f);
+  EU_LIT(aT9, -3.6531571299e-02f); EU_LIT(aT10, 1.6285819933e-02f);
   const eu_f2 s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
   const eu_f2 s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
   const eu_f2 xs = x * (s1 + s2);

@@ -12,6 +12,18 @@
 #include "eu_render_dev.h"
 #include "eu_math2.h"
 
+// EU_FMA_EXPERIMENT (a labelled experiment, never the shipped build): the b-spline weights and the weighted sum
+// with fused multiply-adds - what north_star's tolerance (1 ULP per channel for the interpolation) would
+// allow, against the 0-ULP contract the library keeps. Offsets, deltas and everything in front of
+// them are untouched. EU_MAD(a, b, c) = a * b + c in the contract's two roundings, or fused.
+#ifdef EU_FMA_EXPERIMENT
+#define EU_MAD2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+#define EU_MAD1(a, b, c) __builtin_fmaf((a), (b), (c))
+#else
+#define EU_MAD2(a, b, c) ((a) * (b) + (c))
+#define EU_MAD1(a, b, c) ((a) * (b) + (c))
+#endif
+
 typedef const __attribute__((address_space(4))) float *eu_cptr;   // scalar-cache loads
 
 // weights of both lanes for one axis; DEG 2 and 3 use the literal weight
@@ -23,9 +35,10 @@ __device__ __forceinline__ void eu_weights2(const float *wm, eu_f2 d, eu_f2 *w)
   if constexpr (DEG == 3) {
     const float a = 0x1.555556p-3f, b = 0x1.555556p-1f;
     eu_f2 d2 = d * d, d3 = d2 * d;
-    eu_f2 w0 = a + d * -0.5f; w0 = w0 + d2 * 0.5f; w0 = w0 + d3 * -a;
-    eu_f2 w1 = b - d2;        w1 = w1 + d3 * 0.5f;
-    eu_f2 w2 = a + d * 0.5f;  w2 = w2 + d2 * 0.5f; w2 = w2 + d3 * -0.5f;
+    const eu_f2 mh = { -0.5f, -0.5f }, ph = { 0.5f, 0.5f }, ma = { -a, -a }, pa = { a, a };
+    eu_f2 w0 = EU_MAD2(d, mh, pa); w0 = EU_MAD2(d2, ph, w0); w0 = EU_MAD2(d3, ma, w0);
+    eu_f2 w1 = b - d2;             w1 = EU_MAD2(d3, ph, w1);
+    eu_f2 w2 = EU_MAD2(d, ph, pa); w2 = EU_MAD2(d2, ph, w2); w2 = EU_MAD2(d3, mh, w2);
     w[0] = w0; w[1] = w1; w[2] = w2; w[3] = d3 * a;
   } else if constexpr (DEG == 2) {
     eu_f2 d2 = d * d;
@@ -80,11 +93,11 @@ __device__ __forceinline__ void eu_accumulate1(PTR p0, STRIDE es1,
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       float sum = a[c] * wl0;
-      sum = sum + b[c] * wr0;
+      sum = EU_MAD1(b[c], wr0, sum);
       sum = sum * wl1;
       float sub = c2[c] * wl0;
-      sub = sub + d[c] * wr0;
-      sum = sum + sub * wr1;
+      sub = EU_MAD1(d[c], wr0, sub);
+      sum = EU_MAD1(sub, wr1, sum);
       out[c] = sum;
     }
   } else {
@@ -100,9 +113,9 @@ __device__ __forceinline__ void eu_accumulate1(PTR p0, STRIDE es1,
       for (int c = 0; c < NCH; c++) {
         float r = t[0][c] * wx[0];
 #pragma unroll
-        for (int i = 1; i < order; i++) r = r + wx[i] * t[i][c];
+        for (int i = 1; i < order; i++) r = EU_MAD1(wx[i], t[i][c], r);
         if (j == 0) sum[c] = r * wy[0];
-        else sum[c] = sum[c] + r * wy[j];
+        else sum[c] = EU_MAD1(r, wy[j], sum[c]);
       }
     }
 #pragma unroll

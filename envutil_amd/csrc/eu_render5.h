@@ -88,12 +88,12 @@ __device__ __forceinline__ void eu5_taps(eu_lptr lt, int a, int b, int pitch, co
 #pragma unroll
       for (int i = 1; i < order; i++) {
         const eu_f2 wa = { wx[i].x, wx[i].x }, wb = { wx[i].y, wx[i].y };
-        ra = ra + wa * ta[i].xy; qa = qa + wa * ta[i].zw;
-        rb = rb + wb * tb[i].xy; qb = qb + wb * tb[i].zw;
+        ra = EU_MAD2(wa, ta[i].xy, ra); qa = EU_MAD2(wa, ta[i].zw, qa);
+        rb = EU_MAD2(wb, tb[i].xy, rb); qb = EU_MAD2(wb, tb[i].zw, qb);
       }
       const eu_f2 ya = { wy[j].x, wy[j].x }, yb = { wy[j].y, wy[j].y };
       if (j == 0) { rga = ra * ya; bxa = qa * ya; rgb = rb * yb; bxb = qb * yb; }
-      else { rga = rga + ra * ya; bxa = bxa + qa * ya; rgb = rgb + rb * yb; bxb = bxb + qb * yb; }
+      else { rga = EU_MAD2(ra, ya, rga); bxa = EU_MAD2(qa, ya, bxa); rgb = EU_MAD2(rb, yb, rgb); bxb = EU_MAD2(qb, yb, bxb); }
     }
   }
 }

@@ -12,6 +12,13 @@
 #define EU_TILE_W 64
 #define EU_TILE_H 4
 
+// EU_FMA_EXPERIMENT (a labelled experiment, never the shipped build; eu_packed_dev.h): the weighted sum fused
+#ifdef EU_FMA_EXPERIMENT
+#define EU_MADS(a, b, c) __builtin_fmaf((a), (b), (c))
+#else
+#define EU_MADS(a, b, c) ((a) * (b) + (c))
+#endif
+
 // ---------------------------------------------------------------------------
 // gates: zimt/map.h:184-440
 // ---------------------------------------------------------------------------
@@ -137,11 +144,11 @@ __device__ __forceinline__ void eu_accumulate(const float *wm, float tx, float t
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       float sum = a[c] * wl0;
-      sum = sum + b[c] * wr0;
+      sum = EU_MADS(b[c], wr0, sum);
       sum = sum * wl1;
       float sub = c2[c] * wl0;
-      sub = sub + d[c] * wr0;
-      sum = sum + sub * wr1;
+      sub = EU_MADS(d[c], wr0, sub);
+      sum = EU_MADS(sub, wr1, sum);
       out[c] = sum;
     }
   } else {
@@ -159,9 +166,9 @@ __device__ __forceinline__ void eu_accumulate(const float *wm, float tx, float t
       for (int c = 0; c < NCH; c++) {
         float r = t[0][c] * wx[0];
 #pragma unroll
-        for (int i = 1; i < order; i++) r = r + wx[i] * t[i][c];
+        for (int i = 1; i < order; i++) r = EU_MADS(wx[i], t[i][c], r);
         if (j == 0) sum[c] = r * wy[0];
-        else sum[c] = sum[c] + r * wy[j];
+        else sum[c] = EU_MADS(r, wy[j], sum[c]);
       }
     }
 #pragma unroll
