@@ -51,6 +51,7 @@
 // layout of eu_render_params::wl (ints); every counter on a 64-byte line of its own
 #define EU4_WL_SHARD(s) (16 * (s))                       // entries in list s
 #define EU4_WL_DONE1 (16 * EU4_SHARDS)                   // finished workgroups, direct-gather kernel
+#define EU4_WL_DYN(x) (16 * (EU4_SHARDS + 1 + (x)))       // eu_render5_kernel: next batch of XCD x's second loop
 #define EU4_WL_ENTRIES (16 * (EU4_SHARDS + 16))          // entry k of list s at + k * EU4_SHARDS + s
 #define EU4_UNIT_ROWS 4    // tile rows per XCD unit (32 pixel rows)
 #ifndef EU4_ASM_TAPS
@@ -205,6 +206,13 @@ struct eu4_plan {
   const int *tileplan;    // per tile row of the launch: column table to use, -1: none
   const float *coltab;    // [plan][width][EU4_COL_FLOATS]
   int tiles16;            // wave tiles per tile row
+  // eu_render5_kernel's second loop (the tile rows without a common column plan), dealt out dynamically: the tile
+  // rows XCD x owns in that loop are l2_rows[l2_off[x] .. l2_off[x + 1]) (raster order), a dequeue is one BATCH of
+  // two neighbouring tiles of a row; l2_half = ceil(tiles16 / 2) batches per row, l2_magic = floor(2^40 / l2_half) + 1
+  const int *l2_rows;
+  int l2_off[9];
+  int l2_half;
+  unsigned long long l2_magic;
 #ifdef EU5_STAMPS
   unsigned long long *stamps;   // diagnostic build: 8 s_memtime stamps per tile of eu_render5_kernel
 #endif
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(256, 4) void eu_render4d_kernel(const eu_render_par
   if (threadIdx.x == 0) last = atomicAdd(p.wl + EU4_WL_DONE1, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (last) {
-    for (int i = threadIdx.x; i <= EU4_SHARDS; i += 256)
+    for (int i = threadIdx.x; i <= EU4_SHARDS + 8; i += 256)         // the lists, the counter of this kernel, the staged kernel's queues
       __hip_atomic_store(p.wl + 16 * i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -681,6 +689,8 @@ struct plan_cache {
   float *coltab = nullptr; size_t coltab_cap = 0;
   float *atab = nullptr;
   int planned_rows = 0;      // tile rows with a column plan
+  int *l2_rows = nullptr; size_t l2_cap = 0;
+  int l2_off[9] = {};
   hipStream_t last_stream = nullptr;   // where the plans were last read
 } g4s[EU_MAX_SLOTS];
 // one cache per device slot (eu_api.hip: eu_hip_init_devices)
@@ -789,6 +799,25 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
     if (hipMemcpy(g4.tileplan, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
     g4.planned_rows = 0;
     for (int v : tp) g4.planned_rows += v >= 0;
+    {
+      // the second loop's rows per XCD: units of EU5_UNIT_ROWS tile rows dealt round-robin, as in the first loop
+      std::vector<int> rows[8];
+      for (int r = 0; r < p.tiles_y; r++) {
+        const int m = r >> 1;
+        const bool paired = 2 * m + 1 < p.tiles_y && tp[(size_t)2 * m] >= 0 && tp[(size_t)2 * m] == tp[(size_t)2 * m + 1];
+        if (!paired) rows[(r / EU5_UNIT_ROWS) & 7].push_back(r);
+      }
+      std::vector<int> all;
+      for (int x = 0; x < 8; x++) { g4.l2_off[x] = (int)all.size(); all.insert(all.end(), rows[x].begin(), rows[x].end()); }
+      g4.l2_off[8] = (int)all.size();
+      if (g4.l2_cap < all.size() + 1) {
+        if (g4.l2_rows) (void)hipFree(g4.l2_rows);
+        g4.l2_rows = nullptr; g4.l2_cap = 0;
+        if (hipMalloc((void **)&g4.l2_rows, (all.size() + 1) * sizeof(int)) != hipSuccess) return -1;
+        g4.l2_cap = all.size() + 1;
+      }
+      if (!all.empty() && hipMemcpy(g4.l2_rows, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    }
     for (size_t j = 0; j < plans.size() / 4; j++) {
       float *ct = g4.coltab + j * (size_t)p.width * EU4_COL_FLOATS;
       switch (p.src.degree) {
@@ -805,6 +834,10 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
   }
   w.tileplan = g4.tileplan;
   w.coltab = g4.coltab;
+  w.l2_rows = g4.l2_rows;
+  for (int x = 0; x < 9; x++) w.l2_off[x] = g4.l2_off[x];
+  w.l2_half = (w.tiles16 + 1) / 2;
+  w.l2_magic = (1ull << 40) / (unsigned long long)w.l2_half + 1;
   g4.last_stream = st;
 #ifdef EU5_STAMPS
   // diagnostic build: stamps of every tile, averaged per pass count / plan kind after the launch

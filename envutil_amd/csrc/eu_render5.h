@@ -842,35 +842,49 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
   it.units = (p.tiles_y + EU5_UNIT_ROWS - 1) / EU5_UNIT_ROWS;
   it.start(t0, K);
   if constexpr (PAIRS) {
-    // the rows the first loop left: 16x8 tiles without a column plan (a row whose partner has another plan
-    // does without its own here), each requesting the next one's table values ahead of its stores
-    auto seek = [&](int &ty, int &tcol) -> bool {
-      while (!it.done()) {
-        ty = it.row();
-        if (ty < p.tiles_y && eu5_pair_plan(w.tileplan, p.tiles_y, ty >> 1) < 0) { tcol = it.col(); it.step(); return true; }
-        it.step();
-      }
-      return false;
+    // The rows the first loop left: 16x8 tiles without a column plan (a row whose partner has another plan does
+    // without its own here). Their cost varies - one, two or four passes, a hand-over to the work list - so they
+    // are dealt out DYNAMICALLY: a wave takes the next batch of two neighbouring tiles from its XCD's queue
+    // (w.l2_rows; one returning atomic per batch, requested a tile before its answer is needed). Dealt statically
+    // the waves of a launch finished between 1.77 and 2.46 M cycles (average 2.10 M): a sixth of the launch was
+    // waiting for the waves that had drawn the poles. Each tile requests the next one's table values ahead of its
+    // stores, as in the first loop.
+    int *const queue = p.wl + EU4_WL_DYN(xcd);
+    const int nbatch = (w.l2_off[xcd + 1] - w.l2_off[xcd]) * w.l2_half;
+    const eu5_cint rows2 = (eu5_cint)w.l2_rows + w.l2_off[xcd];
+    auto take = [&]() -> int {                      // the queue's next batch (lane 0's value counts)
+      int v = 0;
+      if (lane0 == 0) v = atomicAdd(queue, 1);
+      return v;                                     // read with readfirstlane where it is needed, not here
     };
-    int ty_a = 0, col_a = 0, ty_b = 0, col_b = 0;
-    bool have_a = seek(ty_a, col_a), have_b = false;
+    auto decode = [&](int j, int &ty, int &tcol) -> bool {
+      if (j >= nbatch) return false;
+      const int r = (int)(((unsigned long long)(unsigned)j * w.l2_magic) >> 40);      // j / l2_half
+      ty = rows2[r]; tcol = 2 * (j - r * w.l2_half);
+      return true;
+    };
+    int ty_a = 0, col_a = 0, ty_n = 0, col_n = 0;
+    bool have = decode(__builtin_amdgcn_readfirstlane(take()), ty_a, col_a);
     eu5_tab8 Ta, Tb;
-    if (have_a) eu5_load8<FAST>(p, ty_a, col_a * EU4_TW, lane0, Ta);
+    if (have) eu5_load8<FAST>(p, ty_a, col_a * EU4_TW, lane0, Ta);
 #pragma unroll 1
-    while (have_a) {
+    while (have) {
+      const int jn_lane = take();                   // in flight across the first tile of this batch
+      const bool second = col_a + 1 < w.tiles16;    // (an odd number of tiles per row: the last batch is one tile)
       {
-        have_b = seek(ty_b, col_b);
         int lane = lane0;
         asm volatile("" : "+v"(lane));
-        eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_a, col_a * EU4_TW, lane, &Ta, have_b, ty_b, col_b * EU4_TW, &Tb);
+        eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_a, col_a * EU4_TW, lane, &Ta, second, ty_a,
+                                                   (col_a + 1) * EU4_TW, &Tb);
       }
-      if (!have_b) break;
-      {
-        have_a = seek(ty_a, col_a);
+      const bool have_n = decode(__builtin_amdgcn_readfirstlane(jn_lane), ty_n, col_n);
+      if (second) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
-        eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_b, col_b * EU4_TW, lane, &Tb, have_a, ty_a, col_a * EU4_TW, &Ta);
-      }
+        eu5_tile<NCH, DEG, PRJ, false, FAST, true>(p, w, atab, tile, nullptr, ty_a, (col_a + 1) * EU4_TW, lane, &Tb, have_n, ty_n,
+                                                   col_n * EU4_TW, &Ta);
+      } else if (have_n) eu5_load8<FAST>(p, ty_n, col_n * EU4_TW, lane0, Ta);
+      ty_a = ty_n; col_a = col_n; have = have_n;
     }
   } else {
     int plan_n = (it.done() || it.row() >= p.tiles_y) ? -2 : (PRJ == EU_SPHERICAL ? ((eu5_cint)w.tileplan)[it.row()] : -1);
