@@ -213,6 +213,11 @@ struct eu4_plan {
   int l2_off[9];
   int l2_half;
   unsigned long long l2_magic;
+  // the first loop's list, the same way: {double row m, its column plan} pairs of XCD x at l1_rows[2 * l1_off[x] ...],
+  // walked with a fixed stride (equal tiles: no queue); l1_magic = floor(2^40 / tiles16) + 1
+  const int *l1_rows;
+  int l1_off[9];
+  unsigned long long l1_magic;
 #ifdef EU5_STAMPS
   unsigned long long *stamps;   // diagnostic build: 8 s_memtime stamps per tile of eu_render5_kernel
 #endif
@@ -588,7 +593,9 @@ __global__ __launch_bounds__(256, 4) void eu_render4d_kernel(const eu_render_par
   }
 }
 
+#ifndef EU4_DIRECT_WGS
 #define EU4_DIRECT_WGS 2048
+#endif
 
 template <int NCH, int DEG, int PRJ>
 static int launch4_ndp(const eu_render_params &p, const eu4_plan &w, hipStream_t st)
@@ -691,6 +698,8 @@ struct plan_cache {
   int planned_rows = 0;      // tile rows with a column plan
   int *l2_rows = nullptr; size_t l2_cap = 0;
   int l2_off[9] = {};
+  int *l1_rows = nullptr; size_t l1_cap = 0;
+  int l1_off[9] = {};
   hipStream_t last_stream = nullptr;   // where the plans were last read
 } g4s[EU_MAX_SLOTS];
 // one cache per device slot (eu_api.hip: eu_hip_init_devices)
@@ -817,6 +826,23 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
         g4.l2_cap = all.size() + 1;
       }
       if (!all.empty() && hipMemcpy(g4.l2_rows, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+      // the first loop's double rows per XCD (units of EU5_UNIT_ROWS / 2 double rows), with their plans
+      std::vector<int> prs[8];
+      for (int m = 0; 2 * m + 1 < p.tiles_y; m++)
+        if (tp[(size_t)2 * m] >= 0 && tp[(size_t)2 * m] == tp[(size_t)2 * m + 1]) {
+          auto &v = prs[(m / (EU5_UNIT_ROWS / 2)) & 7];
+          v.push_back(m); v.push_back(tp[(size_t)2 * m]);
+        }
+      std::vector<int> all1;
+      for (int x = 0; x < 8; x++) { g4.l1_off[x] = (int)all1.size() / 2; all1.insert(all1.end(), prs[x].begin(), prs[x].end()); }
+      g4.l1_off[8] = (int)all1.size() / 2;
+      if (g4.l1_cap < all1.size() + 2) {
+        if (g4.l1_rows) (void)hipFree(g4.l1_rows);
+        g4.l1_rows = nullptr; g4.l1_cap = 0;
+        if (hipMalloc((void **)&g4.l1_rows, (all1.size() + 2) * sizeof(int)) != hipSuccess) return -1;
+        g4.l1_cap = all1.size() + 2;
+      }
+      if (!all1.empty() && hipMemcpy(g4.l1_rows, all1.data(), all1.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
     for (size_t j = 0; j < plans.size() / 4; j++) {
       float *ct = g4.coltab + j * (size_t)p.width * EU4_COL_FLOATS;
@@ -838,6 +864,9 @@ extern "C" int eu_launch_render4(const eu_render_params *pp, const float *h_row,
   for (int x = 0; x < 9; x++) w.l2_off[x] = g4.l2_off[x];
   w.l2_half = (w.tiles16 + 1) / 2;
   w.l2_magic = (1ull << 40) / (unsigned long long)w.l2_half + 1;
+  w.l1_rows = g4.l1_rows;
+  for (int x = 0; x < 9; x++) w.l1_off[x] = g4.l1_off[x];
+  w.l1_magic = (1ull << 40) / (unsigned long long)w.tiles16 + 1;
   g4.last_stream = st;
 #ifdef EU5_STAMPS
   // diagnostic build: stamps of every tile, averaged per pass count / plan kind after the launch

@@ -778,23 +778,22 @@ __global__ __launch_bounds__(64 * EU5_WAVES, EU5_OCC) void eu_render5_kernel(con
   // waits for the plan of the tile it is about to start (measured: 1.6-2.3k cycles per iteration outside
   // the tiles, a quarter of a wave's life).
   if constexpr (PAIRS) {
-    // first the pairs of tile rows with a common column plan, as 16x16 tiles
-    eu5_iter<EU5_UNIT_ROWS / 2> it;
-    it.xcd = xcd; it.tiles16 = w.tiles16;
-    const int rows2 = (p.tiles_y + 1) / 2;
-    it.units = (rows2 + EU5_UNIT_ROWS / 2 - 1) / (EU5_UNIT_ROWS / 2);
-    it.start(t0, K);
-    // moves `it` on to the next position with a pair plan; false when the list is exhausted
+    // first the pairs of tile rows with a common column plan, as 16x16 tiles: position i of the XCD's list
+    // (w.l1_rows: built on the host with the plans, so that no position is looked at only to be skipped) is
+    // column i % tiles16 - rotated by the row, see eu5_iter::col - of double row l1_rows[i / tiles16]
+    const int n1 = (w.l1_off[xcd + 1] - w.l1_off[xcd]) * w.tiles16;
+    const eu5_cint rows1 = (eu5_cint)w.l1_rows + 2 * w.l1_off[xcd];
+    int pos1 = t0;
     auto seek = [&](int &m, int &tcol, int &plan) -> bool {
-      while (!it.done()) {
-        m = it.row();
-        if (m < rows2) {
-          plan = eu5_pair_plan(w.tileplan, p.tiles_y, m);
-          if (plan >= 0) { tcol = it.col(); it.step(); return true; }
-        }
-        it.step();
-      }
-      return false;
+      if (pos1 >= n1) return false;
+      const int r = (int)(((unsigned long long)(unsigned)pos1 * w.l1_magic) >> 40);     // pos1 / tiles16
+      m = rows1[2 * r]; plan = rows1[2 * r + 1];
+      const unsigned h = ((unsigned)m * 0x9E3779B1u) >> 16;
+      int c = pos1 - r * w.tiles16 + (int)((h * (unsigned)w.tiles16) >> 16);
+      if (c >= w.tiles16) c -= w.tiles16;
+      tcol = c;
+      pos1 += K;
+      return true;
     };
     // two copies of the body, the table values alternating between Ta and Tb: handing them from "next" to
     // "current" by assignment is a use, and a use is a wait for the loads that have just been requested
