@@ -462,6 +462,52 @@ __global__ __launch_bounds__(64 * EU4_WAVES0, EU4_OCC0) void eu_render4s_kernel(
     eu4_tile<NCH, DEG, PRJ, false>(p, w, atab, tile, nullptr, tile_y, tile_x * EU4_TW, lane);
 }
 
+// one 16x8 tile by direct gathers: (d+1)^2 taps from global memory, every scalar fallback of the
+// coordinate arithmetic (the work-list kernel's tile)
+template <int NCH, int DEG, int PRJ>
+__device__ __forceinline__ void eu4_direct_tile(const eu_render_params &p, const float *atab, int tile_y, int x0, int lane)
+{
+  const eu_src_dev &s = p.src;
+  const int lx = lane & 7, ly = lane >> 3;
+  const int y = p.row_begin + tile_y * EU4_TH + ly;
+  const bool yin = y < p.row_end;
+  const int yc = yin ? y : p.row_end - 1;
+  const float *rt = p.row + (long long)eu_frame_row(yc, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
+  const int xa = x0 + 2 * lx, xb = xa + 1;
+  const bool va = yin && xa < p.width, vb = yin && xb < p.width;
+  const int xac = xa < p.width ? xa : p.width - 1, xbc = xb < p.width ? xb : p.width - 1;
+  eu_ray2 ry;
+  {
+    const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
+    const eu_f2 c0 = { p.col[xac], p.col[xbc] };
+    if (p.form == EU_FORM_BCA) {
+      const float C0 = rt[6], C1 = rt[7], C2 = rt[8];
+      const float *colB = p.col + p.width;
+      const eu_f2 c1 = { colB[xac], colB[xbc] };
+      ry.x = B0 * c0 + C0 * c1 + A0;
+      ry.y = B1 * c0 + C1 * c1 + A1;
+      ry.z = B2 * c0 + C2 * c1 + A2;
+    } else {
+      ry.x = B0 * c0 + A0;
+      ry.y = B1 * c0 + A1;
+      ry.z = B2 * c0 + A2;
+    }
+    if (p.norm_mode == EU_NORM_DIV) {
+      eu_f2 sqn = ry.x * ry.x; sqn = sqn + ry.y * ry.y; sqn = sqn + ry.z * ry.z;
+      const eu_f2 n = { sqrtf(sqn.x), sqrtf(sqn.y) };
+      ry.x = ry.x / n; ry.y = ry.y / n; ry.z = ry.z / n;
+    }
+  }
+  eu_f2 sx, sy;
+  eu_i2 hit = eu_coord2<PRJ>(s, ry, sx, sy, atab);
+  hit = hit & (eu_i2){ va ? -1 : 0, vb ? -1 : 0 };
+  float pxa[NCH], pxb[NCH];
+  eu_eval2<NCH, DEG>(s, sx, sy, hit, pxa, pxb);
+  float *const orow = p.out + (long long)(yc - p.row_begin) * p.out_stride;
+  if (va) eu_put<NCH>(orow, xa, pxa);
+  if (vb) eu_put<NCH>(orow, xb, pxb);
+}
+
 #include "eu_render5.h"
 
 // ---------------------------------------------------------------------------
@@ -532,8 +578,6 @@ __global__ __launch_bounds__(256, 4) void eu_render4d_kernel(const eu_render_par
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lx = lane & 7, ly = lane >> 3;
-  const eu_src_dev &s = p.src;
   // this wave's list: waves gid, gid + EU4_SHARDS, ... share list gid % EU4_SHARDS
   const int gid = blockIdx.x * EU4_WAVES + wave;
   const int sh = gid & (EU4_SHARDS - 1);
@@ -545,43 +589,7 @@ __global__ __launch_bounds__(256, 4) void eu_render4d_kernel(const eu_render_par
     const int id = __builtin_amdgcn_readfirstlane(p.wl[EU4_WL_ENTRIES + (size_t)k * EU4_SHARDS + sh]);
     const int tile_y = id / w.tiles16;
     const int x0 = (id - tile_y * w.tiles16) * EU4_TW;
-    const int y = p.row_begin + tile_y * EU4_TH + ly;
-    const bool yin = y < p.row_end;
-    const int yc = yin ? y : p.row_end - 1;
-    const float *rt = p.row + (long long)eu_frame_row(yc, p.band_shift, p.band_count, p.band_index) * EU_ROW_FLOATS;
-    const int xa = x0 + 2 * lx, xb = xa + 1;
-    const bool va = yin && xa < p.width, vb = yin && xb < p.width;
-    const int xac = xa < p.width ? xa : p.width - 1, xbc = xb < p.width ? xb : p.width - 1;
-    eu_ray2 ry;
-    {
-      const float A0 = rt[0], A1 = rt[1], A2 = rt[2], B0 = rt[3], B1 = rt[4], B2 = rt[5];
-      const eu_f2 c0 = { p.col[xac], p.col[xbc] };
-      if (p.form == EU_FORM_BCA) {
-        const float C0 = rt[6], C1 = rt[7], C2 = rt[8];
-        const float *colB = p.col + p.width;
-        const eu_f2 c1 = { colB[xac], colB[xbc] };
-        ry.x = B0 * c0 + C0 * c1 + A0;
-        ry.y = B1 * c0 + C1 * c1 + A1;
-        ry.z = B2 * c0 + C2 * c1 + A2;
-      } else {
-        ry.x = B0 * c0 + A0;
-        ry.y = B1 * c0 + A1;
-        ry.z = B2 * c0 + A2;
-      }
-      if (p.norm_mode == EU_NORM_DIV) {
-        eu_f2 sqn = ry.x * ry.x; sqn = sqn + ry.y * ry.y; sqn = sqn + ry.z * ry.z;
-        const eu_f2 n = { sqrtf(sqn.x), sqrtf(sqn.y) };
-        ry.x = ry.x / n; ry.y = ry.y / n; ry.z = ry.z / n;
-      }
-    }
-    eu_f2 sx, sy;
-    eu_i2 hit = eu_coord2<PRJ>(s, ry, sx, sy, atab);
-    hit = hit & (eu_i2){ va ? -1 : 0, vb ? -1 : 0 };
-    float pxa[NCH], pxb[NCH];
-    eu_eval2<NCH, DEG>(s, sx, sy, hit, pxa, pxb);
-    float *const orow = p.out + (long long)(yc - p.row_begin) * p.out_stride;
-    if (va) eu_put<NCH>(orow, xa, pxa);
-    if (vb) eu_put<NCH>(orow, xb, pxb);
+    eu4_direct_tile<NCH, DEG, PRJ>(p, atab, tile_y, x0, lane);
   }
   __shared__ int last;
   __syncthreads();
