@@ -304,6 +304,32 @@ EU_HD float eu_tanf(float x)
 
 EU_HD float eu_sinf(float y) { return eu_sincosf_impl(y, 0); }
 EU_HD float eu_cosf(float y) { return eu_sincosf_impl(y, 1); }
+
+// eu_sinf(y) and eu_cosf(y) for |y| < 120 (the fisheye mounts' phi = atan2f(..) is within +-pi) from ONE
+// reduction and one polynomial of each kind, without branches. Same bits as the two calls:
+//  * below 0.75 sincosf.h skips the reduction; reduce_fast gives n = 0 and xr = fma(-0.0, hpi, x) = x there,
+//    i.e. the same operands for the same polynomials (s = 1, the cosine's constants not negated),
+//  * sinf takes the sine polynomial for even n and the cosine polynomial for odd n, cosf the other way round,
+//    both on (xr * s, x2, n & 2): the two calls evaluate the same two polynomials and swap them,
+//  * negating every constant of the cosine polynomial negates its (rounded) result exactly.
+// Lanes of a wavefront differ in n, so the two separate calls ran both polynomials TWICE each.
+EU_HD void eu_sincosf_120(float y, float *sn, float *cs)
+{
+  const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
+  const double x = (double)y;
+  const uint32_t top = (eu_f2u(y) >> 20) & 0x7ff;
+  const double r = x * hpi_inv;
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  const double xr = eu_fma64(-(double)n, hpi, x);
+  const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+  const double x2 = xr * xr;
+  const float sv = eu_sin_poly(xr * s, x2);
+  float cv = eu_cos_poly(x2, 0);
+  if (n & 2) cv = -cv;
+  *sn = (n & 1) ? cv : sv;
+  *cs = (n & 1) ? sv : cv;
+  if (top <= 0x397) { *sn = y; *cs = 1.0f; }   // |y| < 2^-12
+}
 #endif
 
 // ---------------------------------------------------------------------------

@@ -38,7 +38,7 @@
 template <int NCH, int DEG, bool TWINE, bool GEN = false>
 __global__ __launch_bounds__(256) void eu_render_kernel(const eu_render_params p)
 {
-  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, -EU_UNIT_ROWS);
   if (b < 0) return;
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
   const int lane = threadIdx.x & 63;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void eu_render_lds_kernel(const eu_render_para
   __shared__ __attribute__((aligned(16))) float tile[CAP * TEX];
   __shared__ int bbw[4][4];
 
-  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, -EU_UNIT_ROWS);
   if (b < 0) return;   // whole workgroup: no barrier is skipped by a part of it
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
   const int lane = threadIdx.x & 63;

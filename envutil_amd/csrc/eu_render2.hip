@@ -336,6 +336,13 @@ extern "C" int eu_launch_render2(const eu_render_params *pp, void *stream)
   if (p.src.degree < 1 || p.src.degree > 3 || p.src.es0 != p.nch) return 1;
   static const int unit_rows = [] { const char *e = getenv("EU_HIP_UNIT"); return e ? atoi(e) : EU2_UNIT_ROWS; }();
   p.unit_rows = unit_rows > 0 ? unit_rows : EU2_UNIT_ROWS;
+  // rotated targets and twined jobs walk their units column by column (eu_xcd_tile): their source lines are
+  // shared between vertically neighbouring tiles. EU_HIP_COLMAJOR=0 / 1 forces one walk (A/B runs).
+  {
+    static const int cm_env = [] { const char *e = getenv("EU_HIP_COLMAJOR"); return e ? atoi(e) : -1; }();
+    const bool cm = cm_env >= 0 ? cm_env != 0 : (p.form != EU_FORM_BA || p.twine);
+    if (cm) p.unit_rows = -p.unit_rows;
+  }
   p.tiles_x = (p.width + EU2_TILE_W - 1) / EU2_TILE_W;
   p.tiles_y = (p.row_end - p.row_begin + EU2_TILE_H - 1) / EU2_TILE_H;
   if (p.tiles_x <= 0 || p.tiles_y <= 0) return 0;

@@ -9,6 +9,13 @@
 #include "eu_math.h"
 #include "eu_math2.h"
 
+#ifndef EU_COORD_LEAN
+#define EU_COORD_LEAN 0      // 1: eu_source_coordinate with range-checked FMA forms of its divisions and square roots (measured: config 5 7.3 -> 9.3 ms with EU_COORD_SINCOS, the multi-facet kernel spills three times as much)
+#endif
+#ifndef EU_COORD_SINCOS
+#define EU_COORD_SINCOS 0    // 1: the fisheye mounts sinf and cosf of one angle from one reduction (config 5: 7.3 -> 8.7 ms)
+#endif
+
 #define EU_TILE_W 64
 #define EU_TILE_H 4
 
@@ -290,7 +297,8 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
   float c0, c1;
   switch (s.prj) {
     case EU_SPHERICAL: {       // ray_to_ll_t, geometry.h:278-301
-      float q = sqrtf(rx * rx + rz * rz);
+      const float q2 = rx * rx + rz * rz;
+      const float q = eu_sqrt2_guarded((eu_f2){ q2, q2 }).x;
       // the two atan2f as one packed evaluation (same bits as eu_atan2f, eu_math2.h)
       const eu_f2 a = eu_atan2f_2((eu_f2){ ry, rx }, (eu_f2){ q, rz });
       c1 = a.x;
@@ -298,15 +306,19 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
       break;
     }
     case EU_CYLINDRICAL: {     // ray_to_cyl_t, geometry.h:389-410
-      float q = sqrtf(rx * rx + rz * rz);
-      c1 = ry / q;
+      const float q2 = rx * rx + rz * rz;
+      const float q = eu_sqrt2_guarded((eu_f2){ q2, q2 }).x;
+      c1 = eu_div2_guarded((eu_f2){ ry, ry }, (eu_f2){ q, q }).x;
       c0 = eu_atan2f(rx, rz);
       break;
     }
     case EU_RECTILINEAR:       // ray_to_rect_t, geometry.h:328-345
-      c0 = rx / rz;
-      c1 = ry / rz;
+    {
+      const eu_f2 c = eu_div2_guarded((eu_f2){ rx, ry }, (eu_f2){ rz, rz });
+      c0 = c.x;
+      c1 = c.y;
       break;
+    }
     case EU_STEREOGRAPHIC: {   // ray_to_ster_t, geometry.h:445-465
       float rn = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
       float r = rx * rn, d = ry * rn, f = rz * rn;
@@ -316,12 +328,23 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
       break;
     }
     default: {                 // ray_to_fish_t, geometry.h:513-531
-      float q = sqrtf(rx * rx + ry * ry);
+      const float q2 = rx * rx + ry * ry;
+#if EU_COORD_LEAN
+      const float q = eu_sqrt2_guarded((eu_f2){ q2, q2 }).x;     // sqrtf's bits, a quarter of its cycles
+#else
+      const float q = sqrtf(q2);
+#endif
       const eu_f2 a = eu_atan2f_2((eu_f2){ rz, ry }, (eu_f2){ q, rx });
       float r = (float)1.57079632679489661923 - a.x;
       float phi = a.y;
-      c0 = r * eu_cosf(phi);
-      c1 = r * eu_sinf(phi);
+      float sn, cs;
+#if EU_COORD_SINCOS
+      eu_sincosf_120(phi, &sn, &cs);     // |phi| <= pi: eu_cosf(phi), eu_sinf(phi) from one reduction
+#else
+      cs = eu_cosf(phi); sn = eu_sinf(phi);
+#endif
+      c0 = r * cs;
+      c1 = r * sn;
       break;
     }
   }
@@ -332,7 +355,12 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
     {
       float sqn = c0 * c0;
       sqn = sqn + c1 * c1;
+#if EU_COORD_LEAN
+      const float sq = eu_sqrt2_guarded((eu_f2){ sqn, sqn }).x;
+      float x = eu_div2_guarded((eu_f2){ sq, sq }, (eu_f2){ s.lens_s, s.lens_s }).x;     // sqrtf(sqn) / s.lens_s
+#else
       float x = sqrtf(sqn) / s.lens_s;
+#endif
       float sum = 0.0f, power = 1.0f;
       sum = sum + s.lens_d * power; power = power * x;
       sum = sum + s.lens_c * power; power = power * x;
@@ -353,16 +381,19 @@ __device__ __forceinline__ bool eu_source_coordinate(const eu_src_dev &s, float 
   if (s.prj == EU_RECTILINEAR) mask = mask && (rz > 0.0f);
   // source_t::md_to_spline, environment.h:988-1006: the subtraction is done in
   // double (vec<float> - double), everything after it in float
-  float i0 = (float)((double)c0 - s.tex_x0);
-  i0 = i0 / s.ext_w;
-  i0 = i0 * s.total_w;
-  i0 = i0 - .5f;
-  float i1 = (float)((double)c1 - s.tex_y0);
-  i1 = i1 / s.ext_h;
-  i1 = i1 * s.total_h;
-  i1 = i1 - .5f;
-  sx = i0 - s.win_x_off;
-  sy = i1 - s.win_y_off;
+  // (x and y as one pair: packed operations, and the two divisions as one range-checked FMA sequence -
+  // the bits of `/`, a quarter of its cycles)
+  eu_f2 i = { (float)((double)c0 - s.tex_x0), (float)((double)c1 - s.tex_y0) };
+#if EU_COORD_LEAN
+  i = eu_div2_guarded(i, (eu_f2){ s.ext_w, s.ext_h });
+#else
+  i = i / (eu_f2){ s.ext_w, s.ext_h };
+#endif
+  i = i * (eu_f2){ s.total_w, s.total_h };
+  i = i - .5f;
+  i = i - (eu_f2){ s.win_x_off, s.win_y_off };
+  sx = i.x;
+  sy = i.y;
   return mask;
 }
 
@@ -709,6 +740,21 @@ __device__ __forceinline__ int eu_xcd_tile(int blk, int tiles_x, int tiles_y, in
 {
   const int nx = 8;
   const int xcd = blk % nx, k = blk / nx;
+  if (unit_rows < 0) {
+    // unit_rows < 0: inside a unit of -unit_rows tile rows the tiles are walked COLUMN by column (down the
+    // unit's tile rows, then one tile to the right). What an XCD has in flight is then a compact block of the
+    // frame, and the source lines two vertically neighbouring tiles share - under a rotated or otherwise
+    // slanted mapping most of them - are still in its L2 when the second tile asks: config 4 (32K -> 32K
+    // rotated, twined) FETCH_SIZE x 2 = 12.06 -> 8.26 GB for a 6.44 GB source, HBM traffic 1.44 -> 1.14 times
+    // the algorithmic bytes; config 5 8.25 -> 5.76 GB read and 7.64 -> 7.43 ms. Upright lat/lon jobs keep the
+    // row-major walk (config 2: 0.228 ms row-major, 0.232 column-major).
+    const int ur = -unit_rows;
+    const int unit_tiles = ur * tiles_x;
+    const int ul = k / unit_tiles, iu = k - ul * unit_tiles;
+    const int ix = iu / ur, iy = iu - ix * ur;
+    const int ty = (ul * nx + xcd) * ur + iy;
+    return ty < tiles_y ? ty * tiles_x + ix : -1;
+  }
   const int unit_tiles = unit_rows * tiles_x;
   const int ul = k / unit_tiles, iu = k - ul * unit_tiles;
   const int b = (ul * nx + xcd) * unit_tiles + iu;
@@ -717,6 +763,7 @@ __device__ __forceinline__ int eu_xcd_tile(int blk, int tiles_x, int tiles_y, in
 
 static inline int eu_xcd_grid(int tiles_x, int tiles_y, int unit_rows)
 {
+  if (unit_rows < 0) unit_rows = -unit_rows;
   const int units = (tiles_y + unit_rows - 1) / unit_rows;
   return ((units + 7) / 8) * 8 * unit_rows * tiles_x;
 }

@@ -40,7 +40,42 @@ struct eu_multi_params {
   int hdr, hdr_low, hdr_high;               // _hdr_merge_syn: the facets that rule the shadows / the highlights
   const eu_generic *gen;                    // [nfct] or nullptr: facets stepped by generic_stepper (translation)
   eu_inv_planar inv;                        // tf22 of a --single job
+  const float *rej;                         // [nfct][EU_REJ_STRIDE] or nullptr: early-miss tables (eu_multi_maybe)
 };
+
+// Early miss, second stage (round 3). The exact hit test of a facet costs ~300 vector instructions (two atan2f,
+// sincosf in double, the lens polynomial, md_to_spline) and config 5 ran it 3.1 times per pixel: for every
+// facet whose CORNER cone (rej_cos) holds the ray. The window is a square, two thirds of that cone. For a
+// fisheye facet the planar coordinate is c = R(theta) * (rx, ry) / |(rx, ry)| + shift with R = theta * lens
+// polynomial, and theta is a function of u = rz / |ray|: a table of a LOWER bound of R over bins of u (built
+// on the host in double, 0.2 % below the smallest value of the bin and its neighbours) turns "c.x beyond the
+// right edge" into a few approximate operations (rsq, one table read). Conservative by construction: a ray is
+// dropped only when its coordinate lies beyond an edge moved OUT by 0.1 % of the window, far more than float
+// rounding moves it; everything else takes the exact test as before. Header of a facet's table:
+// [0] u0, [1] bins per unit of u, [2] 0 = no table, [4] [5] shift, [6]..[9] the edges x0 x1 y0 y1 moved out.
+#define EU_REJ_N 1024
+#define EU_REJ_HDR 16
+#define EU_REJ_STRIDE (EU_REJ_HDR + EU_REJ_N)
+__device__ __forceinline__ bool eu_multi_maybe(const eu_multi_params &p, int f, const eu_src_dev &s, float rx, float ry, float rz)
+{
+  const float n2 = rx * rx + ry * ry, n3 = n2 + rz * rz;
+  // stage one: the whole window lies inside a cone around the facet's axis
+  bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(n3));
+  if (p.rej) {
+    const float *tb = p.rej + (size_t)f * EU_REJ_STRIDE;         // f is wave-uniform: scalar loads
+    if (tb[2] != 0.0f) {
+      const float u = rz * __builtin_amdgcn_rsqf(n3);
+      int k = (int)((u - tb[0]) * tb[1]);
+      k = min(max(k, 0), EU_REJ_N - 1);
+      const float lo = tb[EU_REJ_HDR + k];
+      const float ir = __builtin_amdgcn_rsqf(n2);                 // (a ray on the axis: NaN below, no early miss)
+      const float a0 = lo * (rx * ir) + tb[4], a1 = lo * (ry * ir) + tb[5];
+      const bool out = (rx >= 0.0f ? a0 > tb[7] : a0 < tb[6]) || (ry >= 0.0f ? a1 > tb[9] : a1 < tb[8]);
+      maybe = maybe && !out;
+    }
+  }
+  return maybe;
+}
 
 struct eu_pix { int x, y; };
 
@@ -183,7 +218,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       bool hit = true;
       if (masked) {
         // whole wavefront provably outside the facet's window: skip the exact test
-        const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+        const bool maybe = eu_multi_maybe(p, f, s, rx, ry, rz);
         hit = false;
         if (__ballot(maybe)) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
       }
@@ -234,7 +269,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       bool hit = true;
       if (!s.mask_all) {
         // whole wavefront provably outside the facet's window: skip the exact test
-        const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+        const bool maybe = eu_multi_maybe(p, f, s, rx, ry, rz);
         hit = false;
         if (__ballot(maybe)) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
       }
@@ -328,7 +363,7 @@ __device__ __forceinline__ void eu_synopsis_big(const eu_multi_params &p, const 
       const eu_src_dev &s = p.srcs[f];
       bool hit = true;
       if (!s.mask_all) {
-        const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+        const bool maybe = eu_multi_maybe(p, f, s, rx, ry, rz);
         hit = false;
         if (__ballot(maybe)) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
       }
@@ -421,7 +456,7 @@ __device__ __forceinline__ void eu_synopsis_hdr(const eu_multi_params &p, const 
     bool hit = true, any = true;
     if (!s.mask_all) {
       // whole wavefront provably outside the facet's window: its pixel is zero without the exact test
-      const bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz));
+      const bool maybe = eu_multi_maybe(p, f, s, rx, ry, rz);
       hit = false;
       any = __ballot(maybe) != 0;
       if (any) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
@@ -485,7 +520,7 @@ template <int NCH, int DEG, bool PLUS, bool HDR = false, bool GEN = false, bool 
 __global__ __launch_bounds__(256) EU_MULTI_OCC void eu_render_multi_kernel(const eu_multi_params p)
 {
   extern __shared__ float eu_dyn_lds[];
-  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, EU_UNIT_ROWS);
+  const int b = eu_xcd_tile(blockIdx.x, p.tiles_x, p.tiles_y, -EU_UNIT_ROWS);
   if (b < 0) return;
   const int tile_y = b / p.tiles_x, tile_x = b - tile_y * p.tiles_x;
   const int lane = threadIdx.x & 63;

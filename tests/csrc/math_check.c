@@ -101,6 +101,32 @@ long check_sincosf_range(uint32_t first, uint32_t last, int which, uint32_t *fir
   if (first_bad) *first_bad = fb;
   return bad;
 }
+/* eu_sincosf_120 (one reduction, both polynomials, no branch) against the live libm's sinf and cosf:
+ * every float with |y| < 120, both signs */
+long check_sincosf120(uint32_t *first_bad)
+{
+  long bad = 0;
+  uint32_t fb = 0;
+  const float lim = 120.0f;
+  uint32_t last;
+  memcpy(&last, &lim, 4);
+#pragma omp parallel for reduction(+:bad) schedule(static)
+  for (long long u = 0; u < (long long)last; u++) {
+    for (int sg = 0; sg < 2; sg++) {
+      float x, sn, cs;
+      uint32_t uu = (uint32_t)u | (sg ? 0x80000000u : 0u);
+      memcpy(&x, &uu, 4);
+      eu_sincosf_120(x, &sn, &cs);
+      if (!same(sn, sinf(x)) || !same(cs, cosf(x))) {
+        bad++;
+#pragma omp critical
+        if (!fb) fb = uu;
+      }
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return bad;
+}
 int have_sincosf(void) { return 1; }
 #else
 int have_sincosf(void) { return 0; }

@@ -65,6 +65,17 @@ def test_sinf_cosf_all_floats(L, which):
     assert L.check_sincosf_range(0, 0xFFFFFFFF, which, C.byref(first_bad)) == 0, hex(first_bad.value)
 
 
+def test_fused_sincosf_below_120(L):
+    """eu_sincosf_120 (the fisheye mounts' sin and cos of one angle from one reduction): sinf's and cosf's bits
+    for every float below 120 in magnitude"""
+    if not L.have_sincosf():
+        pytest.skip("host CPU without FMA runs a different libm variant")
+    L.check_sincosf120.restype = C.c_long
+    L.check_sincosf120.argtypes = [C.c_void_p]
+    first_bad = C.c_uint32(0)
+    assert L.check_sincosf120(C.byref(first_bad)) == 0, hex(first_bad.value)
+
+
 def test_stereographic_angle_all_floats(L):
     """(float)(M_PI_2 - 2.0 * atan(norm / 2.0)) with libm's double atan
     (stepper.h:1146) against the device restatement, every norm >= 0 incl. inf"""
