@@ -624,7 +624,8 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   bool any_rej = false;
   std::vector<float> rej;
   {
-    static const bool rej_on = [] { const char *e = getenv("EU_HIP_REJ"); return e && e[0] == '1'; }();
+    const char *rje = getenv("EU_HIP_REJ");                  // read on every job
+    const bool rej_on = rje && rje[0] == '1';
     if (rej_on) {
       rej.resize((size_t)nsrc * EU_REJ_STRIDE);
       for (int f = 0; f < nsrc; f++) any_rej |= build_reject_table(sd[f], rej.data() + (size_t)f * EU_REJ_STRIDE);

@@ -339,7 +339,8 @@ extern "C" int eu_launch_render2(const eu_render_params *pp, void *stream)
   // rotated targets and twined jobs walk their units column by column (eu_xcd_tile): their source lines are
   // shared between vertically neighbouring tiles. EU_HIP_COLMAJOR=0 / 1 forces one walk (A/B runs).
   {
-    static const int cm_env = [] { const char *e = getenv("EU_HIP_COLMAJOR"); return e ? atoi(e) : -1; }();
+    const char *cme = getenv("EU_HIP_COLMAJOR");          // read on every launch, like the other A/B switches
+    const int cm_env = cme && cme[0] ? atoi(cme) : -1;
     const bool cm = cm_env >= 0 ? cm_env != 0 : (p.form != EU_FORM_BA || p.twine);
     if (cm) p.unit_rows = -p.unit_rows;
   }

@@ -1,0 +1,83 @@
+"""Round 3's run-time switches, each against the CPU oracle bit for bit and against the other setting:
+  EU_HIP_COLMAJOR  the walk of the XCD units (column by column for rotated / twined jobs, row by row for upright
+                   ones; eu_xcd_tile, eu_render_dev.h) - forced both ways on jobs of both kinds, incl. a frame whose
+                   last unit is partial,
+  EU_HIP_REJ       the multi-facet kernels' second early-miss stage (eu_multi_maybe: a conservative table test in
+                   front of the exact hit test; off by default) - fisheye facets with and without the lens
+                   polynomial and with a shift, voronoi_syn / voronoi_syn_plus / hdr_merge, twining.
+Both are read on every launch."""
+import os
+
+import numpy as np
+import pytest
+
+import envutil_amd as ea
+import euo
+import jobs
+from test_gpu_parity import assert_bits, make_pair, facet_set
+
+pytestmark = pytest.mark.gpu
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("degree", [1, 3])
+@pytest.mark.parametrize("twine", [0, 2])
+def test_column_walk_matches_row_walk_and_oracle(degree, twine):
+    img = jobs.synth_image(512, 256, 3)
+    o, g = make_pair(euo.SPHERICAL, 512, 256, 360.0, img, degree)
+    # 700 x 333: 6 tile columns of 128 (the last ragged), 84 tile rows of 4 = 10 units of 8 and a partial one
+    for ypr in ((0, 0, 0), (25, -10, 5)):
+        a = ea.arguments(ea.SPHERICAL, 700, 333, 360.0, yaw=ypr[0], pitch=ypr[1], roll=ypr[2],
+                         spline_degree=degree, twine=twine)
+        ref = jobs.oracle_render(a, o)
+        outs = []
+        for cm in ("0", "1", None):
+            with env(EU_HIP_COLMAJOR=cm, EU_HIP_R4="0"):
+                outs.append(ea.render(a, g, 3))
+            assert_bits(outs[-1], ref, f"walk {cm} ypr {ypr} twine {twine}")
+
+
+@pytest.mark.parametrize("nch", [3, 4])
+@pytest.mark.parametrize("lens", [None, dict(a=0.01, b=-0.03, c=0.02), dict(a=0.0, b=0.02, c=-0.01, h=0.07, v=-0.04)])
+def test_early_miss_tables_change_nothing(nch, lens):
+    os_, gs = facet_set(euo.FISHEYE, 96, 96, 130.0, nch, 1, lens)
+    for twine in (0, 2):
+        a = ea.arguments(ea.SPHERICAL, 300, 150, 360.0, yaw=10, pitch=4, roll=-2, spline_degree=1, twine=twine)
+        ref = jobs.oracle_render(a, os_)
+        with env(EU_HIP_REJ="1"):
+            got = ea.render(a, gs, nch)
+        assert_bits(got, ref, f"early-miss tables on, nch {nch} lens {lens} twine {twine}")
+        with env(EU_HIP_REJ=None):
+            assert_bits(ea.render(a, gs, nch), got, "tables off against tables on")
+
+
+def test_early_miss_tables_hdr_merge_and_narrow_facets():
+    # narrow facets (most rays miss every facet: the tables decide for most of the frame) and hdr_merge,
+    # where a miss still takes part in the sum
+    os_, gs = facet_set(euo.FISHEYE, 64, 64, 60.0, 3, 1)
+    for syn in (None, "hdr_merge"):
+        kw = dict(synopsis=syn) if syn else {}
+        a = ea.arguments(ea.SPHERICAL, 256, 128, 360.0, spline_degree=1, **kw)
+        ref = jobs.oracle_render(a, os_)
+        with env(EU_HIP_REJ="1"):
+            assert_bits(ea.render(a, gs, 3), ref, f"early-miss tables, synopsis {syn}")
+    assert (ref == 0).mean() > 0.3
