@@ -120,6 +120,14 @@ __device__ __forceinline__ void eu_syn_ray(const eu_multi_params &p, int f, cons
 }
 
 #ifdef EU_MULTI_NCH
+#ifdef EU_MULTI_STAMPS
+// diagnostic build (tools/multi_stamps.py): shader-clock cycles per phase of eu_synopsis's alpha path, summed
+// over the waves of a launch: [0] mask pass, [1] the top facet / all-top evaluation, [2] compositing, [3] waves
+__device__ unsigned long long eu_multi_stamp_acc[4];
+#define EU_MST(k) do { asm volatile("" ::: "memory"); mst_[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define EU_MST(k) do { } while (0)
+#endif
 // per-thread slots in dynamic LDS: [z | sx | sy][facet][256 threads]
 struct eu_slots {
   float *z, *sx, *sy;        // this thread's slot of facet 0; facets are 256 floats apart
@@ -255,6 +263,10 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
   } else {
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 4;
+#ifdef EU_MULTI_STAMPS
+    unsigned long long mst_[4];
+#endif
+    EU_MST(0);
     const unsigned long long live_m = __ballot(live);
     const unsigned live_g = (unsigned)(live_m >> (16 * grp)) & 0xffffu;
     unsigned long long valid = 0, hitm = 0;
@@ -294,6 +306,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
       }
       return best;
     };
+    EU_MST(1);
     const int top = pick(0ull);
 #pragma unroll
     for (int c = 0; c < NCH; c++) out[c] = 0.0f;
@@ -313,6 +326,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
         done = true;
       }
     }
+    EU_MST(2);
     // general path: composite the lane's valid facets, nearest first
     unsigned long long used = 0;
     int layer = 0;
@@ -334,6 +348,15 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
         layer++;
       }
     }
+#ifdef EU_MULTI_STAMPS
+    EU_MST(3);
+    if (lane == 0) {
+      atomicAdd(&eu_multi_stamp_acc[0], mst_[1] - mst_[0]);
+      atomicAdd(&eu_multi_stamp_acc[1], mst_[2] - mst_[1]);
+      atomicAdd(&eu_multi_stamp_acc[2], mst_[3] - mst_[2]);
+      atomicAdd(&eu_multi_stamp_acc[3], 1ull);
+    }
+#endif
   }
 }
 
@@ -602,6 +625,14 @@ static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
 #define EU_CAT2(a, b) a##b
 #define EU_CAT(a, b) EU_CAT2(a, b)
 
+#if defined(EU_MULTI_NCH) && defined(EU_MULTI_STAMPS)
+extern "C" int eu_multi_stamps_read(unsigned long long *out4)
+{
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(eu_multi_stamp_acc), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[4] = { 0, 0, 0, 0 };
+  return hipMemcpyToSymbol(HIP_SYMBOL(eu_multi_stamp_acc), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef EU_MULTI_NCH
 // this translation unit carries the kernels of ONE channel count (the Makefile
 // compiles the file four times, so that the four compile in parallel)
