@@ -82,6 +82,8 @@ struct context {
   hipStream_t last_user = nullptr;                // caller's stream of the last render (eu_hip_sync waits on it too)
   eu_generic *mgen = nullptr; size_t mgen_cap = 0; // multi-facet jobs: the translated facets' transformations
   float *inv_coef = nullptr;                      // --single: the inverse lens model's coefficients (eu_inv_planar)
+  hipEvent_t wl_done = nullptr;                   // behind the last staged launch pair (its work list is free again)
+  hipStream_t wl_stream = nullptr; bool wl_stream_set = false;
   hipStream_t copy = nullptr;                     // D2H of a host-output frame, chunk by chunk
   hipEvent_t chunk_done[4] = { nullptr, nullptr, nullptr, nullptr };
   int *wl = nullptr; size_t wl_cap = 0;           // eu_render4.hip work list (count, done, tile ids)
@@ -770,8 +772,17 @@ int launch_render(const eu_render_params *p, void *st)
     }
     eu_render_params q = *p;
     q.wl = g.wl;
+    // the work list and the persistent kernel's queues belong to ONE launch pair at a time: a job on another
+    // stream than the last staged job's waits for that job's event (same stream: stream order does it)
+    if (g.wl_stream_set && g.wl_stream != (hipStream_t)st && g.wl_done)
+      if (hipStreamWaitEvent((hipStream_t)st, g.wl_done, 0) != hipSuccess) return -1;
     g.launches += 2;
     const int rc = eu_launch_render4(&q, g.h_row.data(), g.h_row.size(), g.plan_gen, r4mode != 1, st);
+    if (rc == 0) {
+      if (!g.wl_done && hipEventCreateWithFlags(&g.wl_done, hipEventDisableTiming) != hipSuccess) return -1;
+      if (hipEventRecord(g.wl_done, (hipStream_t)st) != hipSuccess) return -1;
+      g.wl_stream = (hipStream_t)st; g.wl_stream_set = true;
+    }
     if (rc <= 0) return rc;
     g.launches -= 2;
   }
@@ -1145,7 +1156,10 @@ int eu_hip_render(const eu_target *trg, eu_source *const *srcs, int nsrc, float 
       return fail(EU_ERR_ARGUMENT, "--mask_for: facets whose channel count differs from the target's need a 1- or 2-channel target");
   }
   hipStream_t st = stream ? (hipStream_t)stream : g.stream;
-  g.last_user = stream ? (hipStream_t)stream : nullptr;
+  // g.last_user still names the PREVIOUS job's stream while this job is set up: build_params / build_multi wait
+  // for it before they rewrite tables that job may be reading (it used to be overwritten here, so a job on another
+  // stream rewrote the tables under the previous one: tests/test_gpu_round3_switches.py)
+  struct note_stream { hipStream_t s; ~note_stream() { g.last_user = s; } } note_on_exit{ stream ? (hipStream_t)stream : nullptr };
   if (out_on_device) return render_on_device(trg, srcs, nsrc, out, out_row_stride_bytes, st);
   const size_t rows = (size_t)(trg->row_end - trg->row_begin);
   if (!rows) return EU_OK;

@@ -81,3 +81,30 @@ def test_early_miss_tables_hdr_merge_and_narrow_facets():
         with env(EU_HIP_REJ="1"):
             assert_bits(ea.render(a, gs, 3), ref, f"early-miss tables, synopsis {syn}")
     assert (ref == 0).mean() > 0.3
+
+
+def test_staged_jobs_on_alternating_streams():
+    """The staged kernels' work list and queues are the library's, one launch pair at a time: jobs issued back to
+    back on two different streams (no synchronisation between them) must come out as they do one by one."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    img = jobs.synth_image(512, 256, 3)
+    o, g = make_pair(euo.SPHERICAL, 512, 256, 360.0, img, 3)
+    a1 = ea.arguments(ea.CUBEMAP, 96, 576, 90.0, spline_degree=3)
+    a2 = ea.arguments(ea.CUBEMAP, 80, 480, 90.0, spline_degree=3)
+    dev = torch.device("cuda", 0)
+    with env(EU_HIP_R4="1"):
+        want = [ea.render(a, g, 3) for a in (a1, a2)]
+        outs = [torch.zeros((a.height, a.width, 3), device=dev, dtype=torch.float32) for a in (a1, a2)]
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        tg = [a.target(3, 0, a.height, 0, None) for a in (a1, a2)]
+        srcs = (C.c_void_p * 1)(g.handle)
+        for rep in range(6):
+            k = rep & 1
+            rc = ea.lib().eu_hip_render(C.byref(tg[k]), srcs, 1, C.c_void_p(outs[k].data_ptr()), tg[k].width * 3 * 4,
+                                        1, C.c_void_p(streams[k].cuda_stream))
+            assert rc == 0, ea.lib().eu_hip_last_error()
+        ea.lib().eu_hip_sync()
+        torch.cuda.synchronize()
+    for k in (0, 1):
+        assert_bits(outs[k].cpu().numpy(), want[k], f"job {k} on its own stream")
