@@ -517,7 +517,7 @@ struct multi_params {
 #define EU_REJ_N 1024
 #define EU_REJ_HDR 16
 #define EU_REJ_STRIDE (EU_REJ_HDR + EU_REJ_N)
-static bool build_reject_table(const eu_src_dev &d, float *tab)
+static bool build_reject_table(const eu_src_dev &d, float *tab, bool analytic)
 {
   for (int i = 0; i < EU_REJ_STRIDE; i++) tab[i] = 0.0f;
   if (d.prj != EU_FISHEYE || d.has_shear || d.mask_all || !(d.rej_cos > -1.5f) || !(d.rej_cos < 0.999f)) return false;
@@ -551,6 +551,25 @@ static bool build_reject_table(const eu_src_dev &d, float *tab)
                             std::max(std::fabs((double)d.wex2), std::fabs((double)d.wex3)));
   const double mg = 1e-3 * W;
   tab[0] = (float)u0; tab[1] = (float)(1.0 / du); tab[2] = 1.0f;
+  // the table-free form (EU_HIP_REJ=2): needs R increasing over the cone
+  {
+    bool mono = true;
+    double prev = -1.0;
+    const double tmax = std::acos(std::max(-1.0, u0));
+    for (int i = 0; i <= 4096 && mono; i++) {
+      bool k2 = true;
+      const double r = radius(tmax * i / 4096.0, k2);
+      mono = k2 && r > prev;
+      prev = r;
+    }
+    if (mono && analytic) {
+      tab[2] = 2.0f;
+      const double f = 1.0 - 2e-3;
+      tab[10] = d.has_lcp ? 1.0f / d.lens_s : 0.0f;
+      tab[11] = (float)(f * (d.has_lcp ? d.lens_d : 1.0)); tab[12] = d.has_lcp ? (float)(f * d.lens_c) : 0.0f;
+      tab[13] = d.has_lcp ? (float)(f * d.lens_b) : 0.0f; tab[14] = d.has_lcp ? (float)(f * d.lens_a) : 0.0f;
+    }
+  }
   tab[4] = d.has_shift ? d.lens_h : 0.0f; tab[5] = d.has_shift ? d.lens_v : 0.0f;
   tab[6] = (float)(d.wex0 - mg); tab[7] = (float)(d.wex1 + mg); tab[8] = (float)(d.wex2 - mg); tab[9] = (float)(d.wex3 + mg);
   return true;
@@ -627,10 +646,10 @@ int build_multi(const eu_target *t, eu_source *const *srcs, int nsrc, float *out
   std::vector<float> rej;
   {
     const char *rje = getenv("EU_HIP_REJ");                  // read on every job
-    const bool rej_on = rje && rje[0] == '1';
+    const bool rej_on = rje && (rje[0] == '1' || rje[0] == '2');       // 2: the table-free form where it applies
     if (rej_on) {
       rej.resize((size_t)nsrc * EU_REJ_STRIDE);
-      for (int f = 0; f < nsrc; f++) any_rej |= build_reject_table(sd[f], rej.data() + (size_t)f * EU_REJ_STRIDE);
+      for (int f = 0; f < nsrc; f++) any_rej |= build_reject_table(sd[f], rej.data() + (size_t)f * EU_REJ_STRIDE, rje[0] == '2');
     }
     if (any_rej) {
       if ((rc = grow(&g.mrej, &g.mrej_cap, rej.size()))) return rc;

@@ -63,7 +63,19 @@ __device__ __forceinline__ bool eu_multi_maybe(const eu_multi_params &p, int f, 
   bool maybe = !(rz < s.rej_cos * __builtin_amdgcn_sqrtf(n3));
   if (p.rej) {
     const float *tb = p.rej + (size_t)f * EU_REJ_STRIDE;         // f is wave-uniform: scalar loads
-    if (tb[2] != 0.0f) {
+    if (tb[2] == 2.0f) {
+      // no table: theta = acos(u) >= sqrt(2 t) (1 + t / 12 + 3 t^2 / 160), t = 1 - u (the series of acos in
+      // sqrt(2 t), every term positive: cut off it is a lower bound, 0.13 % low at 65 degrees, 0.9 % at 92), and R is
+      // increasing in theta (checked on the host), so R(bound) <= R(theta). Nothing is read per lane.
+      const float t = 1.0f - rz * __builtin_amdgcn_rsqf(n3);
+      const float th = __builtin_amdgcn_sqrtf(2.0f * t) * (1.0f + t * (0.083333f + t * 0.01875f));
+      const float x = th * tb[10];
+      const float lo = th * (tb[11] + x * (tb[12] + x * (tb[13] + x * tb[14])));          // 0.2 % folded into tb[11..14]
+      const float ir = __builtin_amdgcn_rsqf(n2);
+      const float a0 = lo * (rx * ir) + tb[4], a1 = lo * (ry * ir) + tb[5];
+      const bool out = (rx >= 0.0f ? a0 > tb[7] : a0 < tb[6]) || (ry >= 0.0f ? a1 > tb[9] : a1 < tb[8]);
+      maybe = maybe && !(out && t > 0.0f);
+    } else if (tb[2] != 0.0f) {
       const float u = rz * __builtin_amdgcn_rsqf(n3);
       int k = (int)((u - tb[0]) * tb[1]);
       k = min(max(k, 0), EU_REJ_N - 1);

@@ -66,6 +66,8 @@ def test_early_miss_tables_change_nothing(nch, lens):
         with env(EU_HIP_REJ="1"):
             got = ea.render(a, gs, nch)
         assert_bits(got, ref, f"early-miss tables on, nch {nch} lens {lens} twine {twine}")
+        with env(EU_HIP_REJ="2"):
+            assert_bits(ea.render(a, gs, nch), ref, f"table-free early miss, nch {nch} lens {lens} twine {twine}")
         with env(EU_HIP_REJ=None):
             assert_bits(ea.render(a, gs, nch), got, "tables off against tables on")
 
@@ -78,8 +80,9 @@ def test_early_miss_tables_hdr_merge_and_narrow_facets():
         kw = dict(synopsis=syn) if syn else {}
         a = ea.arguments(ea.SPHERICAL, 256, 128, 360.0, spline_degree=1, **kw)
         ref = jobs.oracle_render(a, os_)
-        with env(EU_HIP_REJ="1"):
-            assert_bits(ea.render(a, gs, 3), ref, f"early-miss tables, synopsis {syn}")
+        for mode in ("1", "2"):
+            with env(EU_HIP_REJ=mode):
+                assert_bits(ea.render(a, gs, 3), ref, f"early miss {mode}, synopsis {syn}")
     assert (ref == 0).mean() > 0.3
 
 
