@@ -21,6 +21,7 @@
 // one slot per thread, and the evaluation of the winning facet(s) starts from
 // them. Facets whose evaluation differs between lanes are handled by a waterfall
 // loop (readlane makes the index uniform, the lanes that want it go together).
+#include <cstring>
 #include "eu_render_dev.h"
 
 #define EU_MULTI_MAXF 64     // facets per job the mask-based alpha compositing takes (one bit each); beyond: eu_synopsis_big
@@ -135,7 +136,7 @@ __device__ __forceinline__ void eu_syn_ray(const eu_multi_params &p, int f, cons
 #ifdef EU_MULTI_STAMPS
 // diagnostic build (tools/multi_stamps.py): shader-clock cycles per phase of eu_synopsis's alpha path, summed
 // over the waves of a launch: [0] mask pass, [1] the top facet / all-top evaluation, [2] compositing, [3] waves
-__device__ unsigned long long eu_multi_stamp_acc[4];
+__device__ unsigned long long eu_multi_stamp_acc[1024 * 4];      // sharded by workgroup: one hot address serialises the launch
 #define EU_MST(k) do { asm volatile("" ::: "memory"); mst_[k] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
 #else
 #define EU_MST(k) do { } while (0)
@@ -277,6 +278,7 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
     const int grp = lane >> 4;
 #ifdef EU_MULTI_STAMPS
     unsigned long long mst_[4];
+    int nexact_ = 0;
 #endif
     EU_MST(0);
     const unsigned long long live_m = __ballot(live);
@@ -295,7 +297,12 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
         // whole wavefront provably outside the facet's window: skip the exact test
         const bool maybe = eu_multi_maybe(p, f, s, rx, ry, rz);
         hit = false;
-        if (__ballot(maybe)) hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+        if (__ballot(maybe)) {
+          hit = eu_source_coordinate(s, rx, ry, rz, sx, sy, face);
+#ifdef EU_MULTI_STAMPS
+          nexact_++;
+#endif
+        }
       }
       sl.z[f * 256] = rz * s.recip_step;
       if (sl.keep) { sl.sx[f * 256] = sx; sl.sy[f * 256] = sy; }
@@ -363,10 +370,11 @@ __device__ __forceinline__ void eu_synopsis(const eu_multi_params &p, const eu_p
 #ifdef EU_MULTI_STAMPS
     EU_MST(3);
     if (lane == 0) {
-      atomicAdd(&eu_multi_stamp_acc[0], mst_[1] - mst_[0]);
-      atomicAdd(&eu_multi_stamp_acc[1], mst_[2] - mst_[1]);
-      atomicAdd(&eu_multi_stamp_acc[2], mst_[3] - mst_[2]);
-      atomicAdd(&eu_multi_stamp_acc[3], 1ull);
+      unsigned long long *acc = eu_multi_stamp_acc + 4 * (blockIdx.x & 1023);
+      atomicAdd(&acc[0], mst_[1] - mst_[0]);
+      atomicAdd(&acc[1], mst_[2] - mst_[1]);
+      atomicAdd(&acc[2], mst_[3] - mst_[2]);
+      atomicAdd(&acc[3], 1ull + ((unsigned long long)nexact_ << 32));      // waves, exact hit tests (wave-level) above bit 32
     }
 #endif
   }
@@ -640,9 +648,11 @@ static int launch_multi_n(const eu_multi_params &p, int degree, hipStream_t st)
 #if defined(EU_MULTI_NCH) && defined(EU_MULTI_STAMPS)
 extern "C" int eu_multi_stamps_read(unsigned long long *out4)
 {
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(eu_multi_stamp_acc), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  unsigned long long z[4] = { 0, 0, 0, 0 };
-  return hipMemcpyToSymbol(HIP_SYMBOL(eu_multi_stamp_acc), z, sizeof z) == hipSuccess ? 0 : -1;
+  static unsigned long long h[1024 * 4];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(eu_multi_stamp_acc), sizeof h) != hipSuccess) return -1;
+  for (int k = 0; k < 4; k++) { out4[k] = 0; for (int i = 0; i < 1024; i++) out4[k] += h[4 * i + k]; }
+  memset(h, 0, sizeof h);
+  return hipMemcpyToSymbol(HIP_SYMBOL(eu_multi_stamp_acc), h, sizeof h) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef EU_MULTI_NCH

@@ -28,6 +28,7 @@ acc = (C.c_ulonglong * 4)()
 ea.lib().eu_multi_stamps_read(acc)            # drop what the launches so far have summed
 ms = ea.render_timed(args, srcs, out.data_ptr(), 4, nch, 0, th, None)
 assert ea.lib().eu_multi_stamps_read(acc) == 0
-w = acc[3]
+w = acc[3] & 0xffffffff
+print("exact hit tests per wave (of %d facets): %.2f" % (len(srcs), (acc[3] >> 32) / w))
 print("kernel %.3f ms (stamped build); waves %d; cycles per wave: mask pass %.0f, top / all-top evaluation %.0f, compositing %.0f"
       % (ms, w, acc[0] / w, acc[1] / w, acc[2] / w))
