@@ -992,7 +992,7 @@ int eu_hip_source_load(const eu_facet *fct, const float *pixels, int spline_degr
   eu_source *s = nullptr;
   if ((rc = new_source(fct, spline_degree, bc0, bc1, support_min, tile_size, &s))) return rc;
   // (a core narrower than the spline's frame on an axis is braced slice by slice in zimt's order,
-  // eu_setup.hip: brace_seq_kernel; such a full-sphere image - at most 4 x 2 pixels - is refused below)
+  // eu_setup.hip: brace_seq_kernel)
   const int nch = s->nch;
   hipError_t e = hipSuccess;
   if (is_cube(fct->projection)) {
@@ -1023,14 +1023,8 @@ int eu_hip_source_load(const eu_facet *fct, const float *pixels, int spline_degr
       // two-axis periodic scheme, everything else bspline::prefilter()
       int spherical = fct->projection == EU_SPHERICAL && std::fabs(fct->hfov - 2.0 * M_PI) < .000001
                       && fct->width == 2 * fct->height;
-      for (int a = 0; a < 2 && spherical; a++) {
-        const long long m = gm.core[a], fr = std::max(gm.left[a], gm.right[a]);
-        if (m != 1 && m < fr + 1) {
-          (void)hipFree(s->dev);
-          delete s;
-          return fail(EU_ERR_UNSUPPORTED, "full-sphere source narrower than the spline's frame: prefilter on the host and adopt");
-        }
-      }
+      // (a full-sphere image smaller than its frame - 2 x 1, 4 x 2, 6 x 3 for degree 3 - takes the sequential forms of
+      // the pole rows and of the horizontal bracing: eu_setup.hip, pole_rows_seq_kernel / brace_seq_kernel)
       rc = eu_launch_prefilter(s->dev, &s->geom, nch, bc0, bc1, prefilter_degree, spherical, g.stream);
       e = hipStreamSynchronize(g.stream);
     }

@@ -699,6 +699,34 @@ __global__ void pole_rows_kernel(float *core, long long W, long long H, long lon
   core[(yt * pitch + x) * nch + c] = core[(ys * pitch + xs) * nch + c];
 }
 
+// the same for an image LOWER than its frame: the reference's loop (environment.h:455-516) fills one row above and
+// one row below per round, each from a source row that only has to lie inside the container - the sources run on
+// into frame rows written in earlier rounds. One thread per column pair (x, x + W/2) and channel walks the rounds.
+__global__ void pole_rows_seq_kernel(float *core, long long W, long long H, long long pitch, int nch,
+                                     long long top, long long bottom)
+{
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long half = W / 2;
+  if ((W & 1) || t >= half * nch) return;
+  const int c = (int)(t % nch);
+  const long long x = t / nch;
+  const long long y0 = -top, y1 = H + bottom;
+  long long us = 0, ut = -1, ls = H - 1, lt = H;
+  auto at = [&](long long xx, long long yy) -> float & { return core[(yy * pitch + xx) * nch + c]; };
+  while (true) {
+    const bool c1 = us >= y0 && us < y1, c2 = ut >= y0 && ut < y1, c3 = ls >= y0 && ls < y1, c4 = lt >= y0 && lt < y1;
+    if (!c2 && !c4) break;
+    if (c2) {
+      if (c1) { const float a = at(x + half, us), b = at(x, us); at(x, ut) = a; at(x + half, ut) = b; us++; }
+      ut--;
+    }
+    if (c4) {
+      if (c3) { const float a = at(x + half, ls), b = at(x, ls); at(x, lt) = a; at(x + half, lt) = b; ls--; }
+      lt++;
+    }
+  }
+}
+
 // ---- cubemap IR ------------------------------------------------------------
 
 __global__ void place_faces_kernel(const float *faces, float *ir, int nch, long long F,
@@ -1090,13 +1118,15 @@ extern "C" int eu_launch_prefilter(float *container, const eu_container *g, int 
       launch_filter_stacked(f2, core, (W / 2) * nch, SX * nch, (int)H, st);
     }
     long long n = (g->left[1] + g->right[1]) * W * nch;
-    if (n > 0)
+    const long long vfr = g->left[1] > g->right[1] ? g->left[1] : g->right[1];
+    if (n > 0 && H < vfr)
+      hipLaunchKernelGGL(pole_rows_seq_kernel, dim3(blocks_for((W / 2) * nch, 64)), dim3(64), 0, st, core, W, H,
+                         SX, nch, (long long)g->left[1], (long long)g->right[1]);
+    else if (n > 0)
       hipLaunchKernelGGL(pole_rows_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, core, W, H,
                          SX, nch, (long long)g->left[1], (long long)g->right[1]);
-    long long nb = (g->left[0] + g->right[0]) * SY * nch;
-    if (nb > 0)
-      hipLaunchKernelGGL(brace_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, st, container, SX,
-                         SY, nch, 0, bc0, (long long)g->left[0], (long long)g->right[0]);
+    // (an image narrower than its frame is braced slice by slice in zimt's order)
+    launch_brace(container, SX, SY, nch, 0, bc0, (long long)g->left[0], (long long)g->right[0], st);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   // bspline::prefilter, zimt/bspline.h:1017-1041 + prefilter.h:133-190

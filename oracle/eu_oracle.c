@@ -690,17 +690,38 @@ void euo_spherical_prefilter(euo_spline *s, int degree)
       free(line);
     }
   }
-  /* over-the-pole frame rows: left half <-> right half */
-  for (long k = 0; k < s->left[1]; k++)
-    for (long x = 0; x < half; x++) {
-      memcpy(core_px(s, x, -1 - k), core_px(s, x + half, k), sizeof(float) * nch);
-      memcpy(core_px(s, x + half, -1 - k), core_px(s, x, k), sizeof(float) * nch);
+  /* over-the-pole frame rows: left half <-> right half, in the reference's order (environment.h:455-516): one
+   * row above and one row below per round, each from a source row that only has to lie inside the CONTAINER - for
+   * an image lower than its frame the sources run on into frame rows written in earlier rounds. For every other
+   * image this is the plain "row -1 - k from row k, row H + k from row H - 1 - k". */
+  {
+    long y0 = -s->left[1], y1 = H + s->right[1];
+    long us = 0, ut = -1, ls = H - 1, lt = H;
+    while (1) {
+      int c1 = us >= y0 && us < y1, c2 = ut >= y0 && ut < y1, c3 = ls >= y0 && ls < y1, c4 = lt >= y0 && lt < y1;
+      if (!c2 && !c4) break;
+      if (c2) {
+        if (c1) {
+          for (long x = 0; x < half; x++) {
+            memcpy(core_px(s, x, ut), core_px(s, x + half, us), sizeof(float) * nch);
+            memcpy(core_px(s, x + half, ut), core_px(s, x, us), sizeof(float) * nch);
+          }
+          us++;
+        }
+        ut--;
+      }
+      if (c4) {
+        if (c3) {
+          for (long x = 0; x < half; x++) {
+            memcpy(core_px(s, x, lt), core_px(s, x + half, ls), sizeof(float) * nch);
+            memcpy(core_px(s, x + half, lt), core_px(s, x, ls), sizeof(float) * nch);
+          }
+          ls--;
+        }
+        lt++;
+      }
     }
-  for (long k = 0; k < s->right[1]; k++)
-    for (long x = 0; x < half; x++) {
-      memcpy(core_px(s, x, H + k), core_px(s, x + half, H - 1 - k), sizeof(float) * nch);
-      memcpy(core_px(s, x + half, H + k), core_px(s, x, H - 1 - k), sizeof(float) * nch);
-    }
+  }
   brace_axis(s, 0);
 }
 

@@ -108,16 +108,18 @@ def test_error_codes_not_aborts():
 
 def test_device_setup_of_images_narrower_than_the_frame():
     """zimt braces slice by slice, outward; a 2-pixel-wide image gets slices copied from slices filled
-    before. The device set-up does the same for such cores (brace_seq_kernel); only a full-sphere image
-    that narrow (at most 4 x 2 pixels) is declined (EU_ERR_UNSUPPORTED)"""
+    before. The device set-up does the same for such cores (brace_seq_kernel) - since round 3 also for a
+    full-sphere image that small (tests/test_gpu_round3_switches.py has the sizes and degrees)"""
     img = jobs.synth_image(2, 9, 3)
     g = ea.Source.load(ea.facet_spec(ea.RECTILINEAR, 2, 9, 60.0), img, 3)
     o = jobs.OracleSource(euo.RECTILINEAR, 2, 9, 60.0, img, 3)
     assert (jobs.bits(g.download().reshape(-1)) == jobs.bits(np.asarray(o.container).reshape(-1))).all()
     a = ea.arguments(ea.RECTILINEAR, 40, 30, 50.0, spline_degree=3)
     assert (jobs.bits(ea.render(a, g)) == jobs.bits(jobs.oracle_render(a, o))).all()
-    with pytest.raises(ea.EuError, match="-3"):
-        ea.Source.load(ea.facet_spec(ea.SPHERICAL, 4, 2, 360.0), jobs.synth_image(4, 2, 3), 3)
+    img = jobs.synth_image(4, 2, 3)
+    gs = ea.Source.load(ea.facet_spec(ea.SPHERICAL, 4, 2, 360.0), img, 3)
+    os_ = jobs.OracleSource(euo.SPHERICAL, 4, 2, 360.0, img, 3)
+    assert (jobs.bits(gs.download().reshape(-1)) == jobs.bits(np.asarray(os_.container).reshape(-1))).all()
     # one pixel wide is fine (a constant along that axis)
     img = jobs.synth_image(1, 20, 3)
     g1 = ea.Source.load(ea.facet_spec(ea.RECTILINEAR, 1, 20, 5.0), img, 3)

@@ -111,3 +111,18 @@ def test_staged_jobs_on_alternating_streams():
         torch.cuda.synchronize()
     for k in (0, 1):
         assert_bits(outs[k].cpu().numpy(), want[k], f"job {k} on its own stream")
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3])
+@pytest.mark.parametrize("w,h", [(2, 1), (4, 2), (6, 3), (8, 4), (10, 5)])
+def test_full_sphere_sources_smaller_than_their_frame(w, h, degree):
+    """A 360 x 180 degree image lower / narrower than the spline's frame (refused until round 3): the over-the-pole
+    rows in the reference's alternating order (environment.h:455-516, sources may be frame rows written a round
+    earlier), the horizontal bracing slice by slice - the device-built container and a render against the oracle."""
+    img = jobs.synth_image(w, h, 3, seed=w)
+    src = ea.Source.load(ea.facet_spec(ea.SPHERICAL, w, h, 360.0), img, degree)
+    osrc = jobs.OracleSource(euo.SPHERICAL, w, h, 360.0, img, degree)
+    assert_bits(src.download(), osrc.container, f"container {w}x{h} degree {degree}")
+    for a in (ea.arguments(ea.CUBEMAP, 16, 96, 90.0, spline_degree=degree),
+              ea.arguments(ea.SPHERICAL, 40, 20, 360.0, yaw=20, pitch=30, roll=-10, spline_degree=degree)):
+        assert_bits(ea.render(a, src, 3), jobs.oracle_render(a, osrc), f"render from {w}x{h} degree {degree}")
