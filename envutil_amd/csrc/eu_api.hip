@@ -281,6 +281,17 @@ int new_source(const eu_facet *fct, int spline_degree, int bc0, int bc1, int sup
   if (is_cube(fct->projection)) {
     // IR image: container == core, REFLECT x REFLECT (cubemap.h:576-583)
     eu::metrics m = eu::make_metrics(fct->width, fct->hfov, support_min, tile_size);
+    // The support frame is all the margin the IR has: a ray at a face's edge picks up at left_frame - 0.5, and a
+    // spline of degree d reaches d / 2 + 1 texels beyond that. With less frame than that (--support_min below its
+    // default of 8 AND a small --tile_size) the reference reads outside its IR array (README.md:1553: the frame
+    // is there "so that interpolators needing support can operate without special-casing"); here the job is refused.
+    // Found by the randomised set-up test at seed 1033: biatan6, 45-pixel faces, degree 4, support 1, tile 16 - frame
+    // 1 / 2 - where the oracle and the device each read their own memory in front of the array.
+    const long need = spline_degree / 2 + 1;
+    if (m.left_frame_px + m.inherent_px < need || m.right_frame_px + m.inherent_px < need) {
+      delete s;
+      return fail(EU_ERR_ARGUMENT, "cubemap support frame (--support_min / --tile_size) too small for the spline degree");
+    }
     s->geom.shape[0] = s->geom.core[0] = m.section_px;
     s->geom.shape[1] = s->geom.core[1] = 6 * m.section_px;
     s->geom.left[0] = s->geom.left[1] = s->geom.right[0] = s->geom.right[1] = 0;

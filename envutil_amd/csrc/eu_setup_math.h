@@ -177,6 +177,7 @@ inline int make_spread(int w, int h, float d, float sigma, float threshold,
 
 struct metrics {
   long face_px, section_px, left_frame_px, right_frame_px;
+  long inherent_px;          // pixels of the face image beyond the 90-degree face proper, per side (hfov > 90 degrees)
   double model_to_px, px_to_model, section_md, refc_md;
 };
 
@@ -193,6 +194,7 @@ inline metrics make_metrics(long face_px, double face_fov, long support_min, lon
   m.model_to_px = double(face_px) / diameter_md;
   m.px_to_model = diameter_md / double(face_px);
   long inherent = (long)std::trunc(m.model_to_px * overscan_md);
+  m.inherent_px = inherent;
   long additional = inherent < support_min ? support_min - inherent : 0;
   long px_min = face_px + 2 * additional;
   long n_tiles = px_min / tile_px;

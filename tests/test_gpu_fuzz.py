@@ -167,8 +167,14 @@ def test_random_device_setup_bit_identical(seed):
         # cubemap IR geometry: --support_min / --tile_size (cubemap.h:233-400)
         smin, tile = int(rng.choice([8, 8, 4, 12, 1])), int(rng.choice([64, 64, 16, 32]))
         o = jobs.OracleSource(sprj, sw, sh, shfov, img, degree, pdeg, support_min=smin, tile=tile)
-        g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch), img, degree, pdeg,
-                           support_min=smin, tile_size=tile)
+        try:
+            g = ea.Source.load(ea.facet_spec(sprj, sw, sh, shfov, nchannels=nch), img, degree, pdeg,
+                               support_min=smin, tile_size=tile)
+        except ea.EuError as e:
+            # a cubemap whose support frame is narrower than the spline reaches is refused (the reference reads
+            # outside its IR array there: nothing to compare)
+            assert "support frame" in str(e) and sprj in (euo.CUBEMAP, euo.BIATAN6) and smin < degree // 2 + 1, str(e)
+            continue
         got = g.download().reshape(-1)
         ref = np.ascontiguousarray(o.container, np.float32).reshape(-1)
         assert got.shape == ref.shape, (sprj, sw, sh, nch, degree, pdeg)

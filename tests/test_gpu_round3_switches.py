@@ -126,3 +126,16 @@ def test_full_sphere_sources_smaller_than_their_frame(w, h, degree):
     for a in (ea.arguments(ea.CUBEMAP, 16, 96, 90.0, spline_degree=degree),
               ea.arguments(ea.SPHERICAL, 40, 20, 360.0, yaw=20, pitch=30, roll=-10, spline_degree=degree)):
         assert_bits(ea.render(a, src, 3), jobs.oracle_render(a, osrc), f"render from {w}x{h} degree {degree}")
+
+
+def test_cubemap_support_narrower_than_the_spline_is_refused():
+    """--support_min 1 --tile_size 16 on 45-pixel faces leaves a frame of 1 / 2 pixels; a degree-4 spline reaches 3
+    texels beyond a pick-up at the face's edge: the reference reads outside its IR array there, the library says
+    so (found by tests/fuzz_wide.py at seed 1033). With the default support of 8 the same source loads."""
+    faces = jobs.synth_cubefaces(45, 3)
+    with pytest.raises(ea.EuError, match="support frame"):
+        ea.Source.load(ea.facet_spec(ea.BIATAN6, 45, 270, 90.0), faces, 4, support_min=1, tile_size=16)
+    g = ea.Source.load(ea.facet_spec(ea.BIATAN6, 45, 270, 90.0), faces, 4)
+    o = jobs.OracleSource(euo.BIATAN6, 45, 270, 90.0, faces, 4)
+    a = ea.arguments(ea.SPHERICAL, 96, 48, 360.0, yaw=158.5, pitch=45.2, spline_degree=4)
+    assert_bits(ea.render(a, g, 3), jobs.oracle_render(a, o), "degree 4 from a biatan6 source with the default support")
