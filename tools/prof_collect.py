@@ -57,4 +57,6 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "r03_prof_*"))):
         o.write(open(summ).read())
         o.write(f"# per step: {ent['kernels']} = {ent['kernel_ms_profile']} ms under the profiler\n")
     print(wl, ent)
+if not out["workloads"]:
+    sys.exit("no gpurun_out/r03_prof_* runs with a summary found: profiles/ left as it is")
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
